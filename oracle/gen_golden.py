@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the real reference libFLAC (TEST INFRASTRUCTURE ONLY).
+
+Runs only where /root/reference exists: `make -C oracle ref` compiles the reference into
+oracle/_ref/libFLAC_ref.so, and this script drives that library through its public stream
+encoder / decoder API (the same calls src/test_libFLAC/encoders.c makes) on small deterministic
+inputs.  What is stored is data only: the input PCM, the encoder settings, and the bytes the
+reference wrote (stream prologue + every frame), plus a few bit-writer / CRC known answers taken
+from calls into the reference's own helper functions.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz and cases.json
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import libflac_ctypes as L  # noqa: E402
+from flac_amd.synth import noise_pcm, synth_pcm  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def make_input(spec):
+    kind = spec["kind"]
+    ch, bps, n = spec["channels"], spec["bps"], spec["n"]
+    if kind == "synth":
+        return synth_pcm(wide_samples=n, sample_rate=spec.get("rate", 44100), channels=ch,
+                         bits_per_sample=bps, seed=spec.get("seed", 1234))
+    if kind == "noise":
+        return noise_pcm(n, ch, bps, spec.get("seed", 7), full_scale=spec.get("full", True))
+    if kind == "wasted":
+        x = synth_pcm(wide_samples=n, channels=ch, bits_per_sample=bps - spec["shift"], seed=spec.get("seed", 5))
+        x = x << spec["shift"]
+        if spec.get("mixed") and ch > 1:
+            x[:, 1] = x[:, 1] >> 1 << 1  # fewer wasted bits on channel 1
+        return x.astype(np.int32)
+    if kind == "const":
+        x = np.empty((n, ch), dtype=np.int32)
+        for c in range(ch):
+            x[:, c] = spec["value"] * (c + 1)
+        return x
+    if kind == "silence":
+        return np.zeros((n, ch), dtype=np.int32)
+    if kind == "square":  # full-scale deflection
+        lim = 2 ** (bps - 1)
+        i = np.arange(n)
+        col = np.where((i // spec.get("period", 3)) % 2 == 0, lim - 1, -lim).astype(np.int32)
+        return np.repeat(col[:, None], ch, axis=1)
+    if kind == "ramp_mod8":  # the reference's encoder API test signal: samples[i] = i & 7
+        return np.repeat((np.arange(n) & 7).astype(np.int32)[:, None], ch, axis=1)
+    if kind == "mixed":  # synth, then a constant stretch, then silence, then noise
+        x = synth_pcm(wide_samples=n, channels=ch, bits_per_sample=bps, seed=spec.get("seed", 11))
+        q = n // 4
+        x[q:2 * q] = 1234
+        x[2 * q:3 * q] = 0
+        x[3 * q:] = noise_pcm(n - 3 * q, ch, bps, 3)
+        return x
+    raise ValueError(kind)
+
+
+def S(n, ch=2, bps=16, **kw):
+    d = dict(kind="synth", n=n, channels=ch, bps=bps)
+    d.update(kw)
+    return d
+
+
+CASES = []
+
+
+def case(name, inp, rate=44100, level=None, blocksize=0, settings=None, chunk=None, planar=False):
+    CASES.append(dict(name=name, input=inp, rate=rate, level=level, blocksize=blocksize,
+                      settings=settings or {}, chunk=chunk, planar=planar))
+
+
+# presets on the benchmark signal: 16-bit stereo 44.1 kHz
+for lv in range(9):
+    n = 6100 if lv < 3 else 13500
+    case("s16_l%d" % lv, S(n), level=lv)
+# loose mid/side needs more than one decision period (15 frames of 1152 at 44.1 kHz)
+case("s16_l1_loose", S(1152 * 34 + 17), level=1)
+case("s16_l4_loose", S(4096 * 11 + 100, seed=77), level=4)
+# 24-bit / 96 kHz stereo (int64 residual datapath, RICE2, wide fixed sums)
+for lv in (0, 2, 5, 8):
+    case("s24_l%d" % lv, S(4096 * 2 + 2048, bps=24, rate=96000), rate=96000, level=lv)
+case("s24_l8_p", S(4096 + 1000, bps=24, rate=96000), rate=96000, level=8, settings={"set_do_qlp_coeff_prec_search": 1})
+case("s16_l8_p", S(4096 * 2 + 123), level=8, settings={"set_do_qlp_coeff_prec_search": 1})
+case("s16_l5_p", S(4096 * 2 + 123), level=5, settings={"set_do_qlp_coeff_prec_search": 1})
+# 8 channels 24-bit 192 kHz, independent channels
+case("c8_24_l8", S(4096 + 700, ch=8, bps=24, rate=192000), rate=192000, level=8)
+case("c8_24_l0", S(1152 * 2 + 5, ch=8, bps=24, rate=192000), rate=192000, level=0)
+case("c3_16_l5", S(4096 + 9, ch=3), level=5)
+# mono / other widths
+case("m16_l2", S(3000, ch=1), level=2)
+case("m16_l8", S(9000, ch=1), level=8)
+case("m8_l5", S(9000, ch=1, bps=8), level=5)
+case("s8_l8", S(9000, bps=8), level=8)
+case("s12_l6", S(9000, bps=12), level=6)
+case("s20_l7", S(9000, bps=20), level=7)
+# block sizes: odd, tiny, with/without LPC, the 8-bit and 16-bit explicit-size header forms
+for bs in (16, 17, 33, 192, 255, 256, 257, 576, 1000, 4608, 8192, 16384):
+    case("s16_l5_bs%d" % bs, S(min(bs * 3 + bs // 3 + 1, 40000)), level=5, blocksize=bs)
+case("s16_l8_bs32", S(100), level=8, blocksize=32)
+case("s16_l2_bs1152x", S(1152 * 3), level=2)              # exact multiple: last block not fractional
+case("s16_l5_bs4096p1", S(4096 * 2 + 1), level=5)          # one-sample final block
+case("s16_l8_bs65535", S(65535 + 100), level=8, blocksize=65535)
+# tiny streams (src/test_streams/main.c:217-296 writes 1- and 5-sample streams)
+for n in (1, 2, 3, 4, 5, 15):
+    case("s16_l8_n%d" % n, S(n), level=8)
+# signal classes
+case("wasted3_l5", dict(kind="wasted", n=9000, channels=2, bps=16, shift=3), level=5)
+case("wasted_mixed_l8", dict(kind="wasted", n=9000, channels=2, bps=16, shift=4, mixed=1), level=8)
+case("wasted24_l8", dict(kind="wasted", n=6000, channels=2, bps=24, shift=8), rate=96000, level=8)
+case("const_l5", dict(kind="const", n=9000, channels=2, bps=16, value=-321), level=5)
+case("silence_l8", dict(kind="silence", n=9000, channels=2, bps=16), level=8)
+case("square_l5", dict(kind="square", n=9000, channels=2, bps=16), level=5)
+case("square24_l8", dict(kind="square", n=9000, channels=2, bps=24, period=5), rate=96000, level=8)
+case("noise16_l8", dict(kind="noise", n=9000, channels=2, bps=16), level=8)
+case("noise16q_l5", dict(kind="noise", n=9000, channels=2, bps=16, full=False), level=5)
+case("noise24_l8", dict(kind="noise", n=6000, channels=2, bps=24), rate=96000, level=8)
+case("noise8_c8_l3", dict(kind="noise", n=3000, channels=8, bps=8), level=3)
+case("mixed_l8", dict(kind="mixed", n=4096 * 8, channels=2, bps=16), level=8)
+case("ramp_mod8_api", dict(kind="ramp_mod8", n=2048, channels=1, bps=16), level=None)
+# option matrix
+case("opt_nomid", S(9000), level=8, settings={"set_do_mid_side_stereo": 0})
+case("opt_l32", S(9000), level=8, settings={"set_max_lpc_order": 32})
+case("opt_l32_24", S(9000, bps=24), rate=96000, level=8, settings={"set_max_lpc_order": 32})
+case("opt_l1", S(9000), level=5, settings={"set_max_lpc_order": 1})
+case("opt_q5", S(9000), level=5, settings={"set_qlp_coeff_precision": 5})
+case("opt_q15", S(9000), level=5, settings={"set_qlp_coeff_precision": 15})
+case("opt_r0", S(9000), level=8, settings={"set_max_residual_partition_order": 0})
+case("opt_r8", S(9000), level=8, settings={"set_max_residual_partition_order": 8})
+case("opt_r3_8", S(9000), level=5, settings={"set_min_residual_partition_order": 3, "set_max_residual_partition_order": 8})
+case("opt_noconst", dict(kind="const", n=5000, channels=2, bps=16, value=99), level=5, settings={"disable_constant_subframes": 1})
+case("opt_nofixed", S(9000), level=2, settings={"disable_fixed_subframes": 1})
+case("opt_noverb", dict(kind="noise", n=5000, channels=2, bps=16), level=5, settings={"disable_verbatim_subframes": 1})
+case("opt_noall", S(9000), level=0, settings={"disable_constant_subframes": 1, "disable_fixed_subframes": 1, "disable_verbatim_subframes": 1})
+case("opt_hann", S(9000), level=8, settings={"set_apodization": "hann"})
+case("opt_rect", S(9000), level=5, settings={"set_apodization": "rectangle"})
+case("opt_multi", S(9000), level=8, settings={"set_apodization": "tukey(0.25);hann;hamming"})
+case("opt_rate_odd", S(5000), rate=44101, level=5)
+case("opt_rate_k", S(5000), rate=64000, level=5)
+case("opt_rate_10", S(5000), rate=100010, level=5)
+case("opt_rate_big", S(5000), rate=655350 // 2 + 1, level=5)
+# API feeding pattern must not matter (src/test_libFLAC/encoders.c:463-476; CLI feeds 2048 at a time)
+case("feed_chunk2048", S(13500), level=8, chunk=2048)
+case("feed_chunk1_planar", S(700), level=5, blocksize=256, chunk=1, planar=True)
+case("feed_planar", S(13500), level=5, planar=True, chunk=4097)
+
+
+def kats(ref):
+    """Known answers from the reference's own bit writer / CRC / UTF-8 helpers."""
+    out = {}
+    rng = np.random.default_rng(99)
+    data = rng.integers(0, 256, size=1000, dtype=np.uint8)
+    buf = data.ctypes.data_as(C.c_void_p)
+    ref.FLAC__crc8.restype = C.c_uint8
+    ref.FLAC__crc16.restype = C.c_uint
+    out["crc_input"] = data.tobytes().hex()
+    out["crc8"] = [int(ref.FLAC__crc8(buf, C.c_uint(n))) for n in (0, 1, 2, 7, 64, 1000)]
+    out["crc16"] = [int(ref.FLAC__crc16(buf, C.c_uint(n))) & 0xffff for n in (0, 1, 2, 7, 64, 1000)]
+    out["crc_lens"] = [0, 1, 2, 7, 64, 1000]
+    # bit writer: raw fields, utf8, rice blocks, unary
+    ref.FLAC__bitwriter_new.restype = C.c_void_p
+    vals = [(0x1, 1), (0x0, 2), (0x15, 5), (0xABCDE, 20), (0xFFFFFFFF, 32), (0x3, 3), (0x12345678, 31), (0, 7)]
+    bw = C.c_void_p(ref.FLAC__bitwriter_new())
+    ref.FLAC__bitwriter_init(bw)
+    for v, n in vals:
+        ref.FLAC__bitwriter_write_raw_uint32(bw, C.c_uint32(v), C.c_uint(n))
+    ref.FLAC__bitwriter_zero_pad_to_byte_boundary(bw)
+    pb, nb = C.POINTER(C.c_ubyte)(), C.c_size_t()
+    ref.FLAC__bitwriter_get_buffer(bw, C.byref(pb), C.byref(nb))
+    out["raw_fields"] = {"vals": vals, "bytes": bytes(pb[:nb.value]).hex()}
+    ref.FLAC__bitwriter_release_buffer(bw)
+    ref.FLAC__bitwriter_delete(bw)
+    utf = {}
+    for v in (0, 0x7f, 0x80, 0x7ff, 0x800, 0xffff, 0x10000, 0x1fffff, 0x200000, 0x3ffffff, 0x4000000, 0x7fffffff):
+        bw = C.c_void_p(ref.FLAC__bitwriter_new())
+        ref.FLAC__bitwriter_init(bw)
+        ref.FLAC__bitwriter_write_utf8_uint32(bw, C.c_uint32(v))
+        ref.FLAC__bitwriter_get_buffer(bw, C.byref(pb), C.byref(nb))
+        utf[str(v)] = bytes(pb[:nb.value]).hex()
+        ref.FLAC__bitwriter_release_buffer(bw)
+        ref.FLAC__bitwriter_delete(bw)
+    for v in (0x80000000, 0xfffffffff):
+        bw = C.c_void_p(ref.FLAC__bitwriter_new())
+        ref.FLAC__bitwriter_init(bw)
+        ref.FLAC__bitwriter_write_utf8_uint64(bw, C.c_uint64(v))
+        ref.FLAC__bitwriter_get_buffer(bw, C.byref(pb), C.byref(nb))
+        utf[str(v)] = bytes(pb[:nb.value]).hex()
+        ref.FLAC__bitwriter_release_buffer(bw)
+        ref.FLAC__bitwriter_delete(bw)
+    out["utf8"] = utf
+    rice = []
+    for k in (0, 1, 4, 9, 14, 20, 30):
+        v = rng.integers(-(1 << max(k, 3)) * 3, (1 << max(k, 3)) * 3, size=50, dtype=np.int64).astype(np.int32)
+        v[7] = 0
+        v[11] = -1
+        if k < 8:
+            v[13] = 40000  # long unary run crossing several words
+        bw = C.c_void_p(ref.FLAC__bitwriter_new())
+        ref.FLAC__bitwriter_init(bw)
+        ref.FLAC__bitwriter_write_raw_uint32(bw, C.c_uint32(5), C.c_uint(3))
+        ref.FLAC__bitwriter_write_rice_signed_block(bw, v.ctypes.data_as(C.c_void_p), C.c_uint(len(v)), C.c_uint(k))
+        ref.FLAC__bitwriter_zero_pad_to_byte_boundary(bw)
+        ref.FLAC__bitwriter_get_buffer(bw, C.byref(pb), C.byref(nb))
+        rice.append({"k": k, "vals": v.tolist(), "bytes": bytes(pb[:nb.value]).hex()})
+        ref.FLAC__bitwriter_release_buffer(bw)
+        ref.FLAC__bitwriter_delete(bw)
+    out["rice"] = rice
+    # window tables
+    ref_win = {}
+    for name, fn, args in (("tukey_0.5_4096", "FLAC__window_tukey", (4096, 0.5)), ("tukey_0.25_1000", "FLAC__window_tukey", (1000, 0.25)),
+                           ("hann_576", "FLAC__window_hann", (576,)), ("hamming_100", "FLAC__window_hamming", (100,)),
+                           ("blackman_100", "FLAC__window_blackman", (100,)), ("welch_33", "FLAC__window_welch", (33,)),
+                           ("triangle_33", "FLAC__window_triangle", (33,)), ("bartlett_32", "FLAC__window_bartlett", (32,))):
+        w = np.zeros(args[0], dtype=np.float32)
+        f = getattr(ref, fn)
+        if len(args) == 2:
+            f(w.ctypes.data_as(C.c_void_p), C.c_int32(args[0]), C.c_float(args[1]))
+        else:
+            f(w.ctypes.data_as(C.c_void_p), C.c_int32(args[0]))
+        ref_win[name] = hashlib.sha256(w.tobytes()).hexdigest()
+    out["windows_sha256"] = ref_win
+    return out
+
+
+def main():
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so")
+    ref = L.load(ref_path)
+    os.makedirs(GOLD, exist_ok=True)
+    index = []
+    total = 0
+    for cs in CASES:
+        inp = cs["input"]
+        pcm = make_input(inp)
+        bps = inp["bps"]
+        meta, frames, ok, _ = L.encode(ref, pcm, bps, cs["rate"], level=cs["level"], blocksize=cs["blocksize"],
+                                       settings=cs["settings"], chunk=cs["chunk"], planar=cs["planar"], seekable=True)
+        assert ok, cs["name"]
+        stream = meta + b"".join(frames)
+        dec, errs, dok = L.decode(ref, stream)
+        assert dok and not errs and np.array_equal(dec, pcm), cs["name"]
+        sizes = np.array([len(f) for f in frames], dtype=np.uint32)
+        small = np.abs(pcm).max(initial=0) < 32768
+        path = os.path.join(GOLD, cs["name"] + ".npz")
+        np.savez_compressed(path, pcm=pcm.astype(np.int16) if small else pcm,
+                            meta=np.frombuffer(meta, dtype=np.uint8),
+                            frames=np.frombuffer(b"".join(frames), dtype=np.uint8), sizes=sizes)
+        total += os.path.getsize(path)
+        entry = dict(cs)
+        entry.update(channels=int(pcm.shape[1]), bps=bps, wide_samples=int(pcm.shape[0]), frames=len(frames),
+                     stream_sha256=hashlib.sha256(stream).hexdigest())
+        index.append(entry)
+        print("%-22s frames=%3d bytes=%7d" % (cs["name"], len(frames), len(stream)))
+    with open(os.path.join(GOLD, "cases.json"), "w") as f:
+        json.dump(index, f, indent=1)
+    with open(os.path.join(GOLD, "kats.json"), "w") as f:
+        json.dump(kats(ref), f, indent=1)
+    print("total fixture bytes: %d" % total)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""ctypes driver for the libFLAC 1.2.1 stream encoder / decoder C API.
+
+Works against any shared object that exports that ABI: the reference library built into
+oracle/_ref/ (to generate golden vectors, in the build container only) and this repository's own
+drop-in library (to test it the way the reference's own API tests do).
+"""
+import ctypes as C
+
+import numpy as np
+
+WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint, C.c_uint, C.c_void_p)
+SEEK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
+TELL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+
+DEC_READ_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.POINTER(C.c_size_t), C.c_void_p)
+DEC_WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.c_void_p)
+DEC_ERROR_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class FrameHeader(C.Structure):
+    """Leading fields of FLAC__Frame (FLAC__FrameHeader, include/FLAC/format.h:446)."""
+    _fields_ = [("blocksize", C.c_uint), ("sample_rate", C.c_uint), ("channels", C.c_uint),
+                ("channel_assignment", C.c_int), ("bits_per_sample", C.c_uint),
+                ("number_type", C.c_int), ("number", C.c_uint64), ("crc", C.c_uint8)]
+
+
+def load(path):
+    lib = C.CDLL(path)
+    lib.FLAC__stream_encoder_new.restype = C.c_void_p
+    lib.FLAC__stream_decoder_new.restype = C.c_void_p
+    for name in ("FLAC__stream_encoder_delete", "FLAC__stream_decoder_delete"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+        getattr(lib, name).restype = None
+    return lib
+
+
+def encode(lib, pcm, bits_per_sample, sample_rate, level=None, blocksize=0, settings=None,
+           chunk=None, planar=False, seekable=False, total_samples_estimate=0):
+    """Encode interleaved int32 pcm (n, channels) through the stream API.
+
+    Returns (metadata_bytes, [frame_bytes, ...], final_state_ok, writes) where writes is the raw
+    list of (bytes, samples, current_frame) callbacks.  With seekable=True seek/tell callbacks are
+    supplied and the returned metadata reflects the finish()-time STREAMINFO rewrite.
+    """
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    n, channels = pcm.shape
+    enc = C.c_void_p(lib.FLAC__stream_encoder_new())
+    u = C.c_uint
+    ok = True
+    ok &= bool(lib.FLAC__stream_encoder_set_streamable_subset(enc, C.c_int(0)))
+    ok &= bool(lib.FLAC__stream_encoder_set_channels(enc, u(channels)))
+    ok &= bool(lib.FLAC__stream_encoder_set_bits_per_sample(enc, u(bits_per_sample)))
+    ok &= bool(lib.FLAC__stream_encoder_set_sample_rate(enc, u(sample_rate)))
+    if level is not None:
+        ok &= bool(lib.FLAC__stream_encoder_set_compression_level(enc, u(level)))
+    if blocksize:
+        ok &= bool(lib.FLAC__stream_encoder_set_blocksize(enc, u(blocksize)))
+    if total_samples_estimate:
+        lib.FLAC__stream_encoder_set_total_samples_estimate(enc, C.c_uint64(total_samples_estimate))
+    for key, val in (settings or {}).items():
+        fn = getattr(lib, "FLAC__stream_encoder_" + key)
+        if key == "set_apodization":
+            ok &= bool(fn(enc, C.c_char_p(val.encode())))
+        elif key.startswith("disable_"):
+            ok &= bool(fn(enc, C.c_int(1 if val else 0)))
+        else:
+            ok &= bool(fn(enc, u(int(val))))
+    assert ok, "a setter failed"
+
+    stream = bytearray()
+    state = {"pos": 0}
+    writes = []
+
+    def on_write(_e, buf, nbytes, samples, frame, _c):
+        data = bytes(buf[:nbytes])
+        writes.append((data, samples, frame))
+        end = state["pos"] + nbytes
+        if end > len(stream):
+            stream.extend(b"\0" * (end - len(stream)))
+        stream[state["pos"]:end] = data
+        state["pos"] = end
+        return 0
+
+    def on_seek(_e, off, _c):
+        state["pos"] = off
+        return 0
+
+    def on_tell(_e, poff, _c):
+        poff[0] = state["pos"]
+        return 0
+
+    wcb = WRITE_CB(on_write)
+    scb = SEEK_CB(on_seek) if seekable else C.cast(None, SEEK_CB)
+    tcb = TELL_CB(on_tell) if seekable else C.cast(None, TELL_CB)
+    st = lib.FLAC__stream_encoder_init_stream(enc, wcb, scb, tcb, None, None)
+    if st != 0:
+        lib.FLAC__stream_encoder_delete(enc)
+        raise RuntimeError("init_stream failed with status %d" % st)
+    if chunk is None:
+        chunk = n if n else 1
+    pos = 0
+    good = True
+    while pos < n and good:
+        m = min(chunk, n - pos)
+        if planar:
+            cols = [np.ascontiguousarray(pcm[pos:pos + m, c]) for c in range(channels)]
+            arr = (C.POINTER(C.c_int32) * channels)(*[c.ctypes.data_as(C.POINTER(C.c_int32)) for c in cols])
+            good = bool(lib.FLAC__stream_encoder_process(enc, arr, u(m)))
+        else:
+            blk = pcm[pos:pos + m]
+            good = bool(lib.FLAC__stream_encoder_process_interleaved(
+                enc, blk.ctypes.data_as(C.POINTER(C.c_int32)), u(m)))
+        pos += m
+    good = bool(lib.FLAC__stream_encoder_finish(enc)) and good
+    lib.FLAC__stream_encoder_delete(enc)
+    frames = [d for d, s, _f in writes if s > 0]
+    meta_len = 0
+    for d, s, _f in writes:
+        if s > 0:
+            break
+        meta_len += len(d)
+    return bytes(stream[:meta_len]), frames, good, writes
+
+
+def decode(lib, stream_bytes, md5_check=True):
+    """Decode a whole FLAC stream through the stream decoder API.
+
+    Returns (pcm int32 (n, channels), list of error codes, finish_ok).
+    """
+    dec = C.c_void_p(lib.FLAC__stream_decoder_new())
+    if md5_check:
+        lib.FLAC__stream_decoder_set_md5_checking(dec, C.c_int(1))
+    data = bytes(stream_bytes)
+    state = {"pos": 0}
+    blocks = []
+    errors = []
+
+    def on_read(_d, buf, pbytes, _c):
+        want = pbytes[0]
+        take = min(want, len(data) - state["pos"])
+        if take == 0:
+            pbytes[0] = 0
+            return 1  # END_OF_STREAM
+        C.memmove(buf, data[state["pos"]:state["pos"] + take], take)
+        state["pos"] += take
+        pbytes[0] = take
+        return 0
+
+    def on_write(_d, frame, buffers, _c):
+        hdr = C.cast(frame, C.POINTER(FrameHeader)).contents
+        bs, ch = hdr.blocksize, hdr.channels
+        blk = np.empty((bs, ch), dtype=np.int32)
+        for c in range(ch):
+            blk[:, c] = np.ctypeslib.as_array(buffers[c], shape=(bs,))
+        blocks.append(blk)
+        return 0
+
+    def on_error(_d, status, _c):
+        errors.append(status)
+
+    rcb, wcb, ecb = DEC_READ_CB(on_read), DEC_WRITE_CB(on_write), DEC_ERROR_CB(on_error)
+    st = lib.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, None, ecb, None)
+    if st != 0:
+        lib.FLAC__stream_decoder_delete(dec)
+        raise RuntimeError("decoder init_stream failed with status %d" % st)
+    ok = bool(lib.FLAC__stream_decoder_process_until_end_of_stream(dec))
+    fin = bool(lib.FLAC__stream_decoder_finish(dec))
+    lib.FLAC__stream_decoder_delete(dec)
+    pcm = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, 1), dtype=np.int32)
+    return pcm, errors, ok and fin
