@@ -1,0 +1,442 @@
+// C ABI of the frame engine: handle management, buffer sizing, kernel sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "enc_kernels.h"
+#include "flac_amd.h"
+#include "flac_amd_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" int fa_fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+extern "C" const char *flacamd_last_error(void) { return g_err; }
+extern "C" const char *flacamd_version(void) { return "flac_amd 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr) \
+	do { \
+		hipError_t e_ = (expr); \
+		if (e_ != hipSuccess) \
+			return fa_fail(FLACAMD_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+// ---------------------------------------------------------------------------------------------
+// CRC tables (crc.c:40-110 holds the same tables as literals; generated here from the polynomials)
+// ---------------------------------------------------------------------------------------------
+static void make_crc_tables(uint16_t t16[256], uint16_t pow16[32], uint8_t t8[256])
+{
+	for (uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i << 8;
+		for (int b = 0; b < 8; b++)
+			c = (c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1);
+		t16[i] = (uint16_t)c;
+		uint32_t d = i;
+		for (int b = 0; b < 8; b++)
+			d = (d & 0x80) ? ((d << 1) ^ 0x07) : (d << 1);
+		t8[i] = (uint8_t)d;
+	}
+	// x^8 mod P, then repeated squaring
+	auto mul = [](uint32_t a, uint32_t b) {
+		uint32_t r = 0;
+		for (int i = 0; i < 16; i++) {
+			if (b & 1) r ^= a;
+			b >>= 1;
+			a <<= 1;
+			if (a & 0x10000) a ^= 0x18005;
+		}
+		return r;
+	};
+	uint32_t p = 0x100;
+	for (int j = 0; j < 32; j++) {
+		pow16[j] = (uint16_t)p;
+		p = mul(p, p);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder handle
+// ---------------------------------------------------------------------------------------------
+struct flacamd_encoder {
+	flacamd_encode_params params;
+	FaEncParams P;
+	int device;
+	uint32_t max_frames;
+	float *windows;
+	FaSubStat *stats;
+	float *autoc;
+	FaLpcCand *cands;
+	int32_t *coefs;
+	FaPlan *plans;
+	uint32_t *assign;
+	uint32_t *slots;
+	uint32_t *frame_bytes;
+	uint64_t *offsets;
+	uint32_t *errflag;    // [0] device error bits, [1] loose mid/side state out
+	// staging for the host-buffer entry point
+	int32_t *stage_pcm;
+	uint8_t *stage_out;
+	size_t stage_out_bytes;
+	int profiling;
+	hipEvent_t ev[FLACAMD_ENC_STAGES + 1];
+	int have_times;
+};
+
+static size_t slot_bytes_for(const flacamd_encode_params &p)
+{
+	// A chosen subframe's estimate never exceeds the verbatim estimate, and its written size
+	// exceeds its estimate by at most half a bit per sample plus one bit per partition.
+	const size_t per_sub = ((size_t)p.blocksize * (p.bits_per_sample + 3) + 7) / 8 + 512;
+	size_t s = 32 + per_sub * p.channels;
+	return (s + 63) / 64 * 64 + 64;
+}
+
+extern "C" size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nframes)
+{
+	return e ? (size_t)e->P.slot_bytes * nframes : 0;
+}
+
+extern "C" uint32_t flacamd_encoder_max_frames(const flacamd_encoder *e) { return e ? e->max_frames : 0; }
+
+extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
+{
+	if (!e)
+		return;
+	(void)hipSetDevice(e->device);
+	(void)hipFree(e->windows);
+	(void)hipFree(e->stats);
+	(void)hipFree(e->autoc);
+	(void)hipFree(e->cands);
+	(void)hipFree(e->coefs);
+	(void)hipFree(e->plans);
+	(void)hipFree(e->assign);
+	(void)hipFree(e->slots);
+	(void)hipFree(e->frame_bytes);
+	(void)hipFree(e->offsets);
+	(void)hipFree(e->errflag);
+	(void)hipFree(e->stage_pcm);
+	(void)hipFree(e->stage_out);
+	for (int i = 0; i <= FLACAMD_ENC_STAGES; i++)
+		if (e->ev[i])
+			(void)hipEventDestroy(e->ev[i]);
+	delete e;
+}
+
+extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int device, uint32_t max_frames, flacamd_encoder **out)
+{
+	if (!pin || !out || max_frames == 0)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_encoder_create: bad arguments");
+	*out = nullptr;
+	flacamd_encode_params p = *pin;
+	int rc = flacamd_params_resolve(&p);
+	if (rc)
+		return rc;
+	if (p.max_residual_partition_order > FLACAMD_MAX_PARTITION_ORDER)
+		return fa_fail(FLACAMD_E_UNSUPPORTED, "max Rice partition order %u exceeds the device limit %d", p.max_residual_partition_order,
+		               FLACAMD_MAX_PARTITION_ORDER);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return fa_fail(FLACAMD_E_DEVICE, "no HIP device available: the FLAC engine needs an AMD GPU");
+	if (device < 0 || device >= ndev)
+		return fa_fail(FLACAMD_E_DEVICE, "HIP device %d out of range (%d present)", device, ndev);
+	HIP_TRY(hipSetDevice(device));
+
+	flacamd_encoder *e = new (std::nothrow) flacamd_encoder();
+	if (!e)
+		return fa_fail(FLACAMD_E_NOMEM, "out of host memory");
+	memset(e, 0, sizeof *e);
+	e->params = p;
+	e->device = device;
+	e->max_frames = max_frames;
+	FaEncParams &P = e->P;
+	P.channels = p.channels;
+	P.bps = p.bits_per_sample;
+	P.sample_rate = p.sample_rate;
+	P.blocksize = p.blocksize;
+	P.do_ms = p.do_mid_side_stereo ? 1 : 0;
+	P.loose_ms = p.loose_mid_side_stereo ? 1 : 0;
+	P.nsignals = p.channels + (P.do_ms ? 2 : 0);
+	// stream_encoder.c:871
+	P.loose_frames = (uint32_t)((double)p.sample_rate * 0.4 / (double)p.blocksize + 0.5);
+	if (P.loose_frames == 0)
+		P.loose_frames = 1;
+	P.max_lpc_order = p.max_lpc_order;
+	P.qlp_precision = p.qlp_coeff_precision;
+	P.prec_search = p.do_qlp_coeff_prec_search ? 1 : 0;
+	P.exhaustive = p.do_exhaustive_model_search ? 1 : 0;
+	P.min_po = p.min_residual_partition_order;
+	P.max_po = p.max_residual_partition_order;
+	P.disable_constant = p.disable_constant_subframes ? 1 : 0;
+	P.disable_fixed = p.disable_fixed_subframes ? 1 : 0;
+	P.disable_verbatim = p.disable_verbatim_subframes ? 1 : 0;
+	P.napod = p.num_apodizations;
+	P.rice_limit = p.bits_per_sample > 16 ? 31 : 15;  // stream_encoder.c:3195
+	uint32_t il = 0;
+	for (uint32_t b = p.blocksize; b >>= 1;)
+		il++;
+	P.wide_fixed = (p.bits_per_sample + il + 1 > 30) ? 1 : 0;  // stream_encoder.c:887
+	P.nprec = P.prec_search ? 11 : 1;
+	P.ncand = P.napod * P.max_lpc_order * P.nprec;
+	P.slot_bytes = (uint32_t)slot_bytes_for(p);
+
+	const size_t F = max_frames, S = P.nsignals;
+#define ALLOC(ptr, bytes) \
+	do { \
+		hipError_t e_ = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 16); \
+		if (e_ != hipSuccess) { \
+			flacamd_encoder_destroy(e); \
+			return fa_fail(FLACAMD_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+		} \
+	} while (0)
+	ALLOC(e->windows, sizeof(float) * P.napod * P.blocksize);
+	ALLOC(e->stats, sizeof(FaSubStat) * F * S);
+	ALLOC(e->autoc, sizeof(float) * F * S * P.napod * (FA_MAX_ORDER + 1));
+	ALLOC(e->cands, sizeof(FaLpcCand) * F * S * P.ncand);
+	ALLOC(e->coefs, sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order);
+	ALLOC(e->plans, sizeof(FaPlan) * F * S);
+	ALLOC(e->assign, sizeof(uint32_t) * F);
+	ALLOC(e->slots, (size_t)P.slot_bytes * F + 64);
+	ALLOC(e->frame_bytes, sizeof(uint32_t) * F);
+	ALLOC(e->offsets, sizeof(uint64_t) * (F + 1));
+	ALLOC(e->errflag, 16);
+#undef ALLOC
+	(void)hipMemset(e->errflag, 0, 16);
+
+	// window tables, built on the host
+	if (P.max_lpc_order > 0) {
+		float *w = (float *)malloc(sizeof(float) * P.blocksize);
+		if (!w) {
+			flacamd_encoder_destroy(e);
+			return fa_fail(FLACAMD_E_NOMEM, "out of host memory");
+		}
+		for (uint32_t a = 0; a < P.napod; a++) {
+			rc = flacamd_window(p.apod_type[a], p.apod_param[a], P.blocksize, w);
+			if (rc == FLACAMD_OK && hipMemcpy(e->windows + (size_t)a * P.blocksize, w, sizeof(float) * P.blocksize, hipMemcpyHostToDevice) != hipSuccess)
+				rc = fa_fail(FLACAMD_E_DEVICE, "window upload failed");
+			if (rc) {
+				free(w);
+				flacamd_encoder_destroy(e);
+				return rc;
+			}
+		}
+		free(w);
+	}
+	uint16_t t16[256], pow16[32];
+	uint8_t t8[256];
+	make_crc_tables(t16, pow16, t8);
+	fa_upload_crc_tables(t16, pow16, t8);
+	for (int i = 0; i <= FLACAMD_ENC_STAGES; i++)
+		if (hipEventCreate(&e->ev[i]) != hipSuccess) {
+			flacamd_encoder_destroy(e);
+			return fa_fail(FLACAMD_E_DEVICE, "hipEventCreate failed");
+		}
+	HIP_TRY(hipDeviceSynchronize());
+	*out = e;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encoder_set_profiling(flacamd_encoder *e, int on)
+{
+	if (!e)
+		return fa_fail(FLACAMD_E_INVALID, "null encoder");
+	e->profiling = on ? 1 : 0;
+	e->have_times = 0;
+	return FLACAMD_OK;
+}
+
+static const char *kEncStage[FLACAMD_ENC_STAGES] = {"analyze", "autoc", "lpc", "search", "decide", "pack", "scan", "compact"};
+extern "C" const char *flacamd_encoder_stage_name(int s) { return (s >= 0 && s < FLACAMD_ENC_STAGES) ? kEncStage[s] : ""; }
+
+extern "C" int flacamd_encoder_stage_ms(flacamd_encoder *e, float ms[FLACAMD_ENC_STAGES])
+{
+	if (!e || !ms)
+		return fa_fail(FLACAMD_E_INVALID, "bad arguments");
+	if (!e->have_times)
+		return fa_fail(FLACAMD_E_INVALID, "no profiled encode has run");
+	HIP_TRY(hipSetDevice(e->device));
+	HIP_TRY(hipEventSynchronize(e->ev[FLACAMD_ENC_STAGES]));
+	for (int i = 0; i < FLACAMD_ENC_STAGES; i++)
+		HIP_TRY(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, uint32_t sample_bytes, uint64_t wide_samples,
+                                     uint32_t first_frame, int is_last, uint32_t *loose_state, void *out_dev, size_t out_capacity,
+                                     uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev, uint32_t *nframes_out, void *stream)
+{
+	if (!e || !pcm_dev || !out_dev)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_encode_frames: null argument");
+	if (sample_bytes < 2 || sample_bytes > 4)
+		return fa_fail(FLACAMD_E_INVALID, "sample_bytes must be 2, 3 or 4");
+	const FaEncParams &P = e->P;
+	if (sample_bytes * 8 < P.bps)
+		return fa_fail(FLACAMD_E_INVALID, "%u-byte samples cannot hold %u bits", sample_bytes, P.bps);
+	const uint64_t full = wide_samples / P.blocksize;
+	const uint32_t rem = (uint32_t)(wide_samples % P.blocksize);
+	if (rem && !is_last)
+		return fa_fail(FLACAMD_E_INVALID, "only the last batch may end in a short block (%u samples left over)", rem);
+	const uint64_t nf = full + (rem ? 1 : 0);
+	if (nframes_out)
+		*nframes_out = (uint32_t)nf;
+	if (nf == 0)
+		return FLACAMD_OK;
+	if (nf > e->max_frames)
+		return fa_fail(FLACAMD_E_INVALID, "batch of %llu frames exceeds the encoder's capacity of %u", (unsigned long long)nf, e->max_frames);
+	if ((uint64_t)first_frame + nf > 0x7fffffffull)
+		return fa_fail(FLACAMD_E_INVALID, "frame number exceeds 31 bits");
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t st = (hipStream_t)stream;
+	FaBatch B;
+	B.wide_samples = wide_samples;
+	B.nframes = (uint32_t)nf;
+	B.first_frame = first_frame;
+	B.sample_bytes = sample_bytes;
+	B.loose_carry = loose_state ? *loose_state : 0;
+	uint32_t *fb = frame_bytes_dev ? frame_bytes_dev : e->frame_bytes;
+	uint64_t *fo = frame_offsets_dev ? frame_offsets_dev : e->offsets;
+	const bool prof = e->profiling != 0;
+	int evi = 0;
+#define STAGE_MARK() \
+	do { \
+		if (prof) \
+			HIP_TRY(hipEventRecord(e->ev[evi++], st)); \
+	} while (0)
+	STAGE_MARK();
+	fa_launch_analyze(P, B, pcm_dev, e->stats, st);
+	STAGE_MARK();
+	if (P.max_lpc_order > 0)
+		fa_launch_autoc(P, B, pcm_dev, e->stats, e->windows, e->autoc, st);
+	STAGE_MARK();
+	if (P.max_lpc_order > 0)
+		fa_launch_lpc(P, B, e->stats, e->autoc, e->cands, e->coefs, st);
+	STAGE_MARK();
+	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, st);
+	STAGE_MARK();
+	fa_launch_decide(P, B, e->plans, e->assign, e->errflag + 1, st);
+	STAGE_MARK();
+	fa_launch_pack(P, B, pcm_dev, e->stats, e->plans, e->assign, e->slots, fb, e->errflag, st);
+	STAGE_MARK();
+	fa_launch_scan(fb, B.nframes, fo, st);
+	STAGE_MARK();
+	fa_launch_compact(P, B, e->slots, fb, fo, (uint8_t *)out_dev, out_capacity, e->errflag, st);
+	STAGE_MARK();
+#undef STAGE_MARK
+	if (prof)
+		e->have_times = 1;
+	HIP_TRY(hipGetLastError());
+	if (loose_state && P.loose_ms) {
+		// the next batch needs this batch's last decision
+		HIP_TRY(hipMemcpyAsync(loose_state, e->errflag + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encoder_status(flacamd_encoder *e)
+{
+	if (!e)
+		return fa_fail(FLACAMD_E_INVALID, "null encoder");
+	HIP_TRY(hipSetDevice(e->device));
+	uint32_t flag = 0;
+	HIP_TRY(hipMemcpy(&flag, e->errflag, sizeof flag, hipMemcpyDeviceToHost));
+	if (flag) {
+		(void)hipMemset(e->errflag, 0, sizeof flag);
+		if (flag & 2)
+			return fa_fail(FLACAMD_E_OVERFLOW, "output buffer too small for the encoded frames");
+		return fa_fail(FLACAMD_E_OVERFLOW, "a frame outgrew its slot (device error bits %u)", flag);
+	}
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm, uint64_t wide_samples, uint32_t first_frame, int is_last,
+                                          uint32_t *loose_state, uint8_t *out, size_t out_capacity, uint32_t *frame_bytes,
+                                          uint32_t *nframes_out, size_t *bytes_out)
+{
+	if (!e || (!pcm && wide_samples) || !out || !frame_bytes)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_encode_frames_host: null argument");
+	if (nframes_out)
+		*nframes_out = 0;
+	if (bytes_out)
+		*bytes_out = 0;
+	if (wide_samples == 0)
+		return FLACAMD_OK;
+	HIP_TRY(hipSetDevice(e->device));
+	const FaEncParams &P = e->P;
+	if (!e->stage_pcm) {
+		const size_t in_bytes = sizeof(int32_t) * (size_t)e->max_frames * P.blocksize * P.channels;
+		e->stage_out_bytes = (size_t)P.slot_bytes * e->max_frames;
+		if (hipMalloc((void **)&e->stage_pcm, in_bytes) != hipSuccess || hipMalloc((void **)&e->stage_out, e->stage_out_bytes) != hipSuccess)
+			return fa_fail(FLACAMD_E_NOMEM, "staging buffers: hipMalloc failed");
+	}
+	if (wide_samples > (uint64_t)e->max_frames * P.blocksize)
+		return fa_fail(FLACAMD_E_INVALID, "batch larger than the encoder's capacity");
+	HIP_TRY(hipMemcpy(e->stage_pcm, pcm, sizeof(int32_t) * wide_samples * P.channels, hipMemcpyHostToDevice));
+	uint32_t nf = 0;
+	int rc = flacamd_encode_frames(e, e->stage_pcm, 4, wide_samples, first_frame, is_last, loose_state, e->stage_out, e->stage_out_bytes,
+	                               nullptr, nullptr, &nf, nullptr);
+	if (rc)
+		return rc;
+	HIP_TRY(hipDeviceSynchronize());
+	rc = flacamd_encoder_status(e);
+	if (rc)
+		return rc;
+	uint64_t total = 0;
+	HIP_TRY(hipMemcpy(frame_bytes, e->frame_bytes, sizeof(uint32_t) * nf, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&total, e->offsets + nf, sizeof total, hipMemcpyDeviceToHost));
+	if (total > out_capacity)
+		return fa_fail(FLACAMD_E_OVERFLOW, "output buffer too small: need %llu bytes", (unsigned long long)total);
+	HIP_TRY(hipMemcpy(out, e->stage_out, total, hipMemcpyDeviceToHost));
+	if (nframes_out)
+		*nframes_out = nf;
+	if (bytes_out)
+		*bytes_out = total;
+	return FLACAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test / debug access to intermediate device results (not part of the public header)
+// ---------------------------------------------------------------------------------------------
+extern "C" int flacamd_debug_read(flacamd_encoder *e, int what, void *dst, size_t bytes)
+{
+	if (!e || !dst)
+		return fa_fail(FLACAMD_E_INVALID, "bad arguments");
+	HIP_TRY(hipSetDevice(e->device));
+	const void *src = nullptr;
+	switch (what) {
+	case 0: src = e->stats; break;
+	case 1: src = e->autoc; break;
+	case 2: src = e->cands; break;
+	case 3: src = e->coefs; break;
+	case 4: src = e->plans; break;
+	case 5: src = e->assign; break;
+	case 6: src = e->frame_bytes; break;
+	default: return fa_fail(FLACAMD_E_INVALID, "unknown debug buffer %d", what);
+	}
+	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+	return FLACAMD_OK;
+}
+
+extern "C" size_t flacamd_debug_sizeof(int what)
+{
+	switch (what) {
+	case 0: return sizeof(FaSubStat);
+	case 2: return sizeof(FaLpcCand);
+	case 4: return sizeof(FaPlan);
+	default: return 0;
+	}
+}

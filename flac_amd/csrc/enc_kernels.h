@@ -1,0 +1,25 @@
+// Launchers of the encoder kernels (enc_kernels.hip).
+#ifndef FLAC_AMD_ENC_KERNELS_H
+#define FLAC_AMD_ENC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "flac_amd_internal.h"
+
+size_t fa_search_lds_bytes(void);
+void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
+void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st);
+void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,
+                     hipStream_t st);
+void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stats, const float *autoc, FaLpcCand *cands, int32_t *coefs,
+                   hipStream_t st);
+void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
+                      const int32_t *coefs, FaPlan *plans, hipStream_t st);
+void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st);
+void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st);
+void fa_launch_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets, hipStream_t st);
+void fa_launch_compact(const FaEncParams &P, const FaBatch &B, const uint32_t *slots, const uint32_t *frame_bytes, const uint64_t *offsets,
+                       uint8_t *out, uint64_t out_capacity, uint32_t *errflag, hipStream_t st);
+
+#endif

@@ -1,0 +1,164 @@
+/*
+ * flac_amd.h - C ABI of the MI355X FLAC frame engine (device-resident batch interface).
+ *
+ * This is the thin layer between host C code and the HIP kernels.  The libFLAC-compatible
+ * stream API (flac_amd_stream.h) is written on top of it; callers that already hold PCM or FLAC
+ * bytes in device memory (the benchmark, multi-GPU sharding) call it directly.
+ *
+ * Plain C types only.  Every function returns 0 on success or a negative FLACAMD_E_* code;
+ * flacamd_last_error() gives a thread-local message.  Citations are to the reference tree.
+ */
+#ifndef FLAC_AMD_H
+#define FLAC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLACAMD_MAX_CHANNELS 8
+#define FLACAMD_MAX_LPC_ORDER 32
+#define FLACAMD_MAX_APODIZATIONS 32
+/* Largest Rice partition order the device path evaluates (the FLAC subset limit,
+ * include/FLAC/format.h:119 FLAC__SUBSET_MAX_RICE_PARTITION_ORDER). */
+#define FLACAMD_MAX_PARTITION_ORDER 8
+
+enum {
+	FLACAMD_OK = 0,
+	FLACAMD_E_INVALID = -1,      /* bad argument or settings the reference's init would refuse */
+	FLACAMD_E_UNSUPPORTED = -2,  /* legal for the reference, outside this engine's device limits */
+	FLACAMD_E_DEVICE = -3,       /* HIP runtime error, or no HIP device */
+	FLACAMD_E_NOMEM = -4,
+	FLACAMD_E_OVERFLOW = -5,     /* output buffer too small */
+	FLACAMD_E_STREAM = -6        /* undecodable input (decoder) */
+};
+
+/* Apodization codes; same order as FLAC__ApodizationFunction
+ * (src/libFLAC/include/protected/stream_encoder.h:46-62). */
+enum {
+	FLACAMD_APOD_BARTLETT = 0, FLACAMD_APOD_BARTLETT_HANN, FLACAMD_APOD_BLACKMAN,
+	FLACAMD_APOD_BLACKMAN_HARRIS_4TERM_92DB, FLACAMD_APOD_CONNES, FLACAMD_APOD_FLATTOP,
+	FLACAMD_APOD_GAUSS, FLACAMD_APOD_HAMMING, FLACAMD_APOD_HANN, FLACAMD_APOD_KAISER_BESSEL,
+	FLACAMD_APOD_NUTTALL, FLACAMD_APOD_RECTANGLE, FLACAMD_APOD_TRIANGLE, FLACAMD_APOD_TUKEY,
+	FLACAMD_APOD_WELCH
+};
+
+/* Encoder settings, the fields of FLAC__StreamEncoderProtected that shape a frame
+ * (src/libFLAC/include/protected/stream_encoder.h:78-108), after init-time resolution. */
+typedef struct {
+	uint32_t channels;
+	uint32_t bits_per_sample;
+	uint32_t sample_rate;
+	uint32_t blocksize;
+	uint32_t do_mid_side_stereo;
+	uint32_t loose_mid_side_stereo;
+	uint32_t max_lpc_order;
+	uint32_t qlp_coeff_precision;
+	uint32_t do_qlp_coeff_prec_search;
+	uint32_t do_exhaustive_model_search;
+	uint32_t min_residual_partition_order;
+	uint32_t max_residual_partition_order;
+	uint32_t disable_constant_subframes;
+	uint32_t disable_fixed_subframes;
+	uint32_t disable_verbatim_subframes;
+	uint32_t num_apodizations;
+	uint32_t apod_type[FLACAMD_MAX_APODIZATIONS];
+	float    apod_param[FLACAMD_MAX_APODIZATIONS];
+} flacamd_encode_params;
+
+/* replaces FLAC__stream_encoder_set_compression_level (src/libFLAC/stream_encoder.c:1458) followed
+ * by the defaulting rules of init_stream_internal_ (:663-759).  blocksize 0 = preset default. */
+int flacamd_params_preset(flacamd_encode_params *p, uint32_t level, uint32_t channels,
+                          uint32_t bits_per_sample, uint32_t sample_rate, uint32_t blocksize);
+/* replaces the validation / defaulting block of init_stream_internal_ (stream_encoder.c:660-759)
+ * for settings filled in by hand.  Returns FLACAMD_E_INVALID where init would fail. */
+int flacamd_params_resolve(flacamd_encode_params *p);
+/* replaces the window generators FLAC__window_* (src/libFLAC/window.c:49-223): fills window[L]. */
+int flacamd_window(uint32_t apod_type, float apod_param, uint32_t L, float *window);
+
+typedef struct flacamd_encoder flacamd_encoder;
+
+/* replaces resize_buffers_ (stream_encoder.c:2245): allocates every device buffer for batches of
+ * up to max_frames frames on HIP device `device`, uploads the window tables.  No other entry
+ * point allocates device memory. */
+int flacamd_encoder_create(const flacamd_encode_params *p, int device, uint32_t max_frames,
+                           flacamd_encoder **out);
+void flacamd_encoder_destroy(flacamd_encoder *e);
+/* bytes of output that max_frames frames can need at worst */
+size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nframes);
+uint32_t flacamd_encoder_max_frames(const flacamd_encoder *e);
+
+/* replaces process_frame_ (stream_encoder.c:2861) for a whole batch of consecutive frames.
+ *   pcm_dev        interleaved PCM in device memory, `wide_samples` wide samples, each sample
+ *                  sample_bytes wide (2: int16, 3: packed little-endian int24, 4: int32)
+ *   wide_samples   full blocks, plus (only when is_last != 0) a final short block
+ *   first_frame    frame number of the first frame of this batch (stream_encoder.c:2947)
+ *   loose_state    in/out: channel assignment of the last loose-mid/side leader frame carried
+ *                  between batches (stream_encoder.c:2954-2961,3159); may be NULL
+ *   out_dev        device buffer, frames written back to back
+ *   frame_bytes_dev / frame_offsets_dev   device arrays [nframes] / [nframes+1] (offsets may be NULL)
+ *   stream         a hipStream_t, or NULL for the default stream
+ * The call enqueues work on `stream` and returns; *nframes_out is known on return. */
+int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, uint32_t sample_bytes,
+                          uint64_t wide_samples, uint32_t first_frame, int is_last,
+                          uint32_t *loose_state, void *out_dev, size_t out_capacity,
+                          uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev,
+                          uint32_t *nframes_out, void *stream);
+/* Same, host buffers in and out (int32 interleaved PCM, as FLAC__stream_encoder_process_interleaved
+ * receives it, stream_encoder.c:2020); synchronous.  frame_bytes has room for max_frames. */
+int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm, uint64_t wide_samples,
+                               uint32_t first_frame, int is_last, uint32_t *loose_state,
+                               uint8_t *out, size_t out_capacity, uint32_t *frame_bytes,
+                               uint32_t *nframes_out, size_t *bytes_out);
+/* After an encode has completed: any device-side error flag (0 = none). */
+int flacamd_encoder_status(flacamd_encoder *e);
+/* Time, in ms, spent in the named stage during the last flacamd_encode_frames call that ran with
+ * profiling enabled (flacamd_encoder_set_profiling): stages 0..FLACAMD_ENC_STAGES-1. */
+#define FLACAMD_ENC_STAGES 8
+int flacamd_encoder_set_profiling(flacamd_encoder *e, int on);
+int flacamd_encoder_stage_ms(flacamd_encoder *e, float ms[FLACAMD_ENC_STAGES]);
+const char *flacamd_encoder_stage_name(int stage);
+
+/* ---- decoder ---------------------------------------------------------------------------- */
+typedef struct flacamd_decoder flacamd_decoder;
+
+/* One stream's description for batch decode: where its frames lie in the input buffer. */
+typedef struct {
+	uint64_t byte_offset;     /* first frame's offset in flac_dev */
+	uint64_t byte_length;     /* bytes of frame data */
+	uint64_t sample_offset;   /* where this stream's first wide sample goes in the output */
+	uint64_t total_samples;   /* wide samples expected (0 = unknown: decode what is there) */
+} flacamd_stream_desc;
+
+/* channels / bits_per_sample / max_blocksize come from STREAMINFO (stream_decoder.c:1423
+ * read_metadata_); all streams of one decoder share them. */
+int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sample, uint32_t max_blocksize,
+                           int device, uint64_t max_input_bytes, uint32_t max_frames,
+                           flacamd_decoder **out);
+void flacamd_decoder_destroy(flacamd_decoder *d);
+/* replaces frame_sync_ + read_frame_ (stream_decoder.c:1941,1996) for a batch of streams whose
+ * bytes are resident in device memory.  Output: interleaved PCM, out_sample_bytes wide (2 or 4),
+ * at each stream's sample_offset.  frames_out / status per frame are kept on the device and
+ * summarised by flacamd_decoder_result. */
+int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_dev, uint64_t flac_bytes,
+                           const flacamd_stream_desc *streams_host, uint32_t nstreams,
+                           void *pcm_out_dev, uint32_t out_sample_bytes, uint64_t out_capacity_wide,
+                           void *stream);
+/* Blocks until the decode finished; reports frames decoded, wide samples written and the number
+ * of frames whose CRC-16 or structure was bad (those are zero-filled, stream_decoder.c:2105-2113). */
+int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint64_t *wide_samples,
+                           uint32_t *bad_frames);
+#define FLACAMD_DEC_STAGES 4
+int flacamd_decoder_set_profiling(flacamd_decoder *d, int on);
+int flacamd_decoder_stage_ms(flacamd_decoder *d, float ms[FLACAMD_DEC_STAGES]);
+const char *flacamd_decoder_stage_name(int stage);
+
+const char *flacamd_last_error(void);
+const char *flacamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -10,6 +10,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 APOD_CODES = {"tukey": 0, "hann": 1, "rectangle": 2, "hamming": 3, "blackman": 4, "welch": 5,
               "triangle": 6, "bartlett": 7}
 
+APOD_NAMES = {v: k for k, v in APOD_CODES.items()}
+
 SETTER_TO_FIELD = {
     "set_do_mid_side_stereo": "do_mid_side_stereo",
     "set_loose_mid_side_stereo": "loose_mid_side_stereo",
