@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Benchmark of the FLAC hot path on MI355X: `flac -8` frame encode (and decode) of synthetic PCM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the whole encode pipeline over one batch: a 600 s 16-bit / 44.1 kHz stereo
+stream (26.46 M wide samples, 6460 frames of 4096) that already lies in HBM as interleaved int16.
+With N > 1 every rank owns the frames [rank*6460, (rank+1)*6460) of an N-times longer stream
+(weak scaling); the only exchange is an all-gather of per-rank byte totals for the stream offsets.
+
+Rank 0 prints one JSON line; see DESIGN.md for what each field is computed from.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SECONDS = 600.0
+RATE = 44100
+CHANNELS = 2
+BPS = 16
+LEVEL = 8
+HBM_PEAK_GBS = 8000.0
+
+
+def make_pcm(seed, seconds):
+    from flac_amd.synth import synth_pcm
+    return synth_pcm(seconds=seconds, sample_rate=RATE, channels=CHANNELS, bits_per_sample=BPS, seed=seed)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the real reference libFLAC (oracle/_ref, compiled from the reference's sources in
+# the build container) when it is present, else this repo's CPU restatement; one process per core.
+# ---------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    kind, seconds, seed = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    pcm = make_pcm(seed, seconds)
+    t0 = time.perf_counter()
+    if kind == "reference":
+        import libflac_ctypes as L
+        ref = L.load(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so"))
+        _meta, frames, ok, _ = L.encode(ref, pcm, BPS, RATE, level=LEVEL, chunk=1 << 20)
+        assert ok
+    else:
+        import oracle_lib as O
+        p = O.preset(LEVEL, CHANNELS, BPS, RATE)
+        frames, _ = O.encode_frames(p, pcm)
+    dt = time.perf_counter() - t0
+    return dt, sum(len(f) for f in frames), pcm.shape[0] * CHANNELS
+
+
+def cpu_baseline(seconds=60.0):
+    import multiprocessing as mp
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so")) else "port"
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(16, cores))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(kind, seconds, 1234 + i) for i in range(cores)])
+    wall_all = time.perf_counter() - t0
+    slowest = max(r[0] for r in res)
+    samples = sum(r[2] for r in res)
+    return {
+        "value": samples / slowest / 1e6,
+        "unit": "MSamples/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d processes x %.0f s of the same synthetic 16-bit/44.1kHz stereo signal, flac -8, encode only; "
+                  "throughput = all samples / slowest process (%.2f s; pool wall %.2f s)" % (cores, seconds, slowest, wall_all),
+        "per_core": samples / cores / slowest / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=SECONDS, help="stream length per GPU (default: the 600 s workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import flac_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: this rank's shard of the stream, resident in HBM as interleaved int16 ----
+    pcm32 = make_pcm(1234 + 1000 * rank, args.seconds)
+    wide = pcm32.shape[0]
+    params = flac_amd.preset(LEVEL, CHANNELS, BPS, RATE)
+    bs = params.blocksize
+    nframes = (wide + bs - 1) // bs
+    first_frame = rank * nframes
+    pcm_dev = torch.from_numpy(pcm32.astype(np.int16)).to(dev)
+    enc = flac_amd.Encoder(params, device=local_rank, max_frames=nframes)
+    out_cap = enc.max_output_bytes(nframes)
+    out_dev = torch.empty(out_cap, dtype=torch.uint8, device=dev)
+    fbytes_dev = torch.zeros(nframes, dtype=torch.int32, device=dev)
+    offs_dev = torch.zeros(nframes + 1, dtype=torch.int64, device=dev)
+    totals = torch.zeros(world, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        enc.encode_device(pcm_dev.data_ptr(), 2, wide, out_dev.data_ptr(), out_cap, fbytes_dev.data_ptr(),
+                          offs_dev.data_ptr(), first_frame=first_frame, is_last=True, stream=stream)
+        if world > 1:
+            # stream offsets of the shards: all-gather of the per-rank byte totals over RCCL
+            dist.all_gather_into_tensor(totals, offs_dev[nframes:nframes + 1])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    enc.status()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    samples_per_step = wide * CHANNELS * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+    flac_bytes = int(offs_dev[nframes].item())
+
+    # ---- per-kernel durations, HIP events on the launch stream, separate passes ----
+    enc.set_profiling(True)
+    acc = {}
+    nprof = max(3, min(10, args.steps))
+    for _ in range(nprof):
+        enc.encode_device(pcm_dev.data_ptr(), 2, wide, out_dev.data_ptr(), out_cap, fbytes_dev.data_ptr(),
+                          offs_dev.data_ptr(), first_frame=first_frame, is_last=True, stream=stream)
+        torch.cuda.synchronize()
+        for k, v in enc.stage_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / nprof
+    enc.set_profiling(False)
+    dominant = max(acc, key=acc.get)
+    alg_bytes = wide * CHANNELS * (BPS // 8) + flac_bytes  # PCM read once at container width + frames written once
+    achieved = alg_bytes / (acc[dominant] * 1e-3) / 1e9
+    pipeline_gbs = alg_bytes / (sum(acc.values()) * 1e-3) / 1e9
+
+    result = {
+        "metric": "encode/decode MSamples/s per node at -8 (1/2/4/8 GPU); bytes vs reference",
+        "value": value,
+        "unit": "MSamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: flac -8 (max LPC order 12, tukey(0.5), Rice partition order 0-6), 16-bit/44.1kHz stereo, "
+                        "blocksize 4096, %.0f s (%d frames) per GPU, PCM resident in HBM as int16" % (args.seconds, nframes),
+            "what": "encode",
+            "frames_per_gpu": nframes,
+            "samples_per_step": samples_per_step,
+            "flac_bytes_per_gpu": flac_bytes,
+            "compression_ratio": flac_bytes / (wide * CHANNELS * 2),
+            "sharding": "contiguous frame ranges per GPU; all-gather of byte totals" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dominant,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": acc,
+            "all_kernels_achieved": pipeline_gbs,
+            "all_kernels_frac": pipeline_gbs / HBM_PEAK_GBS,
+        },
+    }
+
+    # ---- decode of the same stream (device resident), reported beside the encode number ----
+    if not args.no_decode and hasattr(flac_amd.lib(), "flacamd_decode_streams"):
+        try:
+            result["decode"] = bench_decode(torch, flac_amd, dev, local_rank, world, dist, out_dev, flac_bytes, wide, bs,
+                                            nframes, args, pcm_dev)
+        except Exception as exc:  # the encode line must still be printed
+            result["decode"] = {"error": str(exc)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline()
+        # the same bounded sample through the GPU path: output bytes vs the CPU run
+        sample = make_pcm(1234, 60.0)
+        genc = flac_amd.Encoder(params, device=local_rank, max_frames=(sample.shape[0] + bs - 1) // bs)
+        gframes, _ = genc.encode_host(sample)
+        genc.close()
+        kind, seconds, seed = cb["kind"], 60.0, 1234
+        _dt, cpu_bytes, _n = _cpu_worker((kind, seconds, seed))
+        gpu_bytes = sum(len(f) for f in gframes)
+        result["cpu_baseline"] = cb
+        result["bytes_vs_reference"] = {"gpu_bytes": gpu_bytes, "cpu_bytes": cpu_bytes,
+                                        "delta_percent": 100.0 * (gpu_bytes - cpu_bytes) / cpu_bytes}
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev):
+    dec = flac_amd.Decoder(CHANNELS, BPS, bs, device=local_rank, max_input_bytes=flac_bytes + 64, max_frames=nframes + 16)
+    out = torch.zeros(wide * CHANNELS, dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    # the encoder numbered this rank's frames from rank*nframes; tell the decoder where sample 0 is
+    first_sample = int(os.environ.get("RANK", "0")) * nframes * bs
+    streams = [(0, flac_bytes, 0, wide, first_sample)]
+
+    def step():
+        dec.decode_device(flac_dev.data_ptr(), flac_bytes, streams, out.data_ptr(), 2, wide, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    frames, nwide, bad = dec.result()
+    exact = bool(torch.equal(out.view(-1, CHANNELS), pcm_dev))
+    dec.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    ms = dec.stage_ms()
+    dec.close()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    alg = flac_bytes + wide * CHANNELS * 2
+    dom = max(ms, key=ms.get)
+    return {
+        "value": wide * CHANNELS * world * args.steps / elapsed / 1e6,
+        "unit": "MSamples/s",
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "frames": frames, "bad_frames": bad, "bit_exact_vs_input": exact,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": alg / (ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ms},
+    }
+
+
+if __name__ == "__main__":
+    main()

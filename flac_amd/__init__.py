@@ -31,7 +31,7 @@ class EncodeParams(C.Structure):
 
 class StreamDesc(C.Structure):
     _fields_ = [("byte_offset", C.c_uint64), ("byte_length", C.c_uint64),
-                ("sample_offset", C.c_uint64), ("total_samples", C.c_uint64)]
+                ("sample_offset", C.c_uint64), ("total_samples", C.c_uint64), ("first_sample", C.c_uint64)]
 
 
 class FlacAmdError(RuntimeError):
@@ -195,10 +195,23 @@ class Decoder:
             pass
 
     def decode_device(self, flac_ptr, flac_bytes, streams, out_ptr, out_sample_bytes, out_capacity_wide, stream=None):
-        arr = (StreamDesc * len(streams))(*[StreamDesc(*s) for s in streams])
+        arr = (StreamDesc * len(streams))(*[StreamDesc(*(tuple(s) + (0,) * (5 - len(s)))) for s in streams])
         _check(lib().flacamd_decode_streams(self._h, C.c_void_p(flac_ptr), C.c_uint64(flac_bytes), arr, len(streams),
                                             C.c_void_p(out_ptr), out_sample_bytes, C.c_uint64(out_capacity_wide),
                                             C.c_void_p(stream or 0)))
+
+    def decode_host(self, flac_bytes, streams, out_capacity_wide, out_sample_bytes=4):
+        """flac_bytes: the frame data of one or more streams; streams: (byte_offset, byte_length,
+        sample_offset, total_samples[, first_sample]).  Returns (pcm (n, channels), frames, wide, bad)."""
+        buf = np.frombuffer(flac_bytes, dtype=np.uint8)
+        arr = (StreamDesc * len(streams))(*[StreamDesc(*(tuple(s) + (0,) * (5 - len(s)))) for s in streams])
+        out = np.zeros((out_capacity_wide, self.channels), dtype=np.int16 if out_sample_bytes == 2 else np.int32)
+        frames, wide, bad = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+        _check(lib().flacamd_decode_streams_host(
+            self._h, buf.ctypes.data_as(C.c_void_p), C.c_uint64(len(flac_bytes)), arr, len(streams),
+            out.ctypes.data_as(C.c_void_p), out_sample_bytes, C.c_uint64(out_capacity_wide),
+            C.byref(frames), C.byref(wide), C.byref(bad)))
+        return out, frames.value, wide.value, bad.value
 
     def result(self):
         frames, wide, bad = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)

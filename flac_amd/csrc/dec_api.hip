@@ -1,0 +1,283 @@
+// C ABI of the batch decoder: handle management and kernel sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "dec_kernels.h"
+#include "flac_amd.h"
+#include "flac_amd_internal.h"
+
+#define HIP_TRY(expr) \
+	do { \
+		hipError_t e_ = (expr); \
+		if (e_ != hipSuccess) \
+			return fa_fail(FLACAMD_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+struct flacamd_decoder {
+	int device;
+	uint32_t channels, bps, max_blocksize, max_frames;
+	uint64_t max_input_bytes;
+	uint32_t max_streams;
+	FaStream *streams;
+	uint32_t *block_counts;
+	uint64_t *block_offsets;
+	FaFrameCand *cands;
+	uint32_t *ncand;                // [0] count, [1] overflow flag
+	int32_t *tmp;
+	unsigned long long *result;     // good frames, wide samples, bad candidates
+	int profiling, have_times;
+	hipEvent_t ev[FLACAMD_DEC_STAGES + 1];
+	hipStream_t last_stream;
+	// staging for the host-buffer entry point
+	uint8_t *stage_in;
+	void *stage_out;
+	size_t stage_out_bytes;
+};
+
+extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
+{
+	if (!d)
+		return;
+	(void)hipSetDevice(d->device);
+	(void)hipFree(d->streams);
+	(void)hipFree(d->block_counts);
+	(void)hipFree(d->block_offsets);
+	(void)hipFree(d->cands);
+	(void)hipFree(d->ncand);
+	(void)hipFree(d->tmp);
+	(void)hipFree(d->result);
+	(void)hipFree(d->stage_in);
+	(void)hipFree(d->stage_out);
+	for (int i = 0; i <= FLACAMD_DEC_STAGES; i++)
+		if (d->ev[i])
+			(void)hipEventDestroy(d->ev[i]);
+	delete d;
+}
+
+extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sample, uint32_t max_blocksize, int device,
+                                      uint64_t max_input_bytes, uint32_t max_frames, flacamd_decoder **out)
+{
+	if (!out)
+		return fa_fail(FLACAMD_E_INVALID, "null out pointer");
+	*out = nullptr;
+	if (channels == 0 || channels > FLACAMD_MAX_CHANNELS)
+		return fa_fail(FLACAMD_E_INVALID, "invalid number of channels %u", channels);
+	if (bits_per_sample < 4 || bits_per_sample > 32)
+		return fa_fail(FLACAMD_E_INVALID, "invalid bits per sample %u", bits_per_sample);
+	if (max_blocksize < 1 || max_blocksize > 65535)
+		return fa_fail(FLACAMD_E_INVALID, "invalid blocksize %u", max_blocksize);
+	if (max_frames == 0 || max_input_bytes == 0)
+		return fa_fail(FLACAMD_E_INVALID, "empty capacity");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return fa_fail(FLACAMD_E_DEVICE, "no HIP device available: the FLAC engine needs an AMD GPU");
+	if (device < 0 || device >= ndev)
+		return fa_fail(FLACAMD_E_DEVICE, "HIP device %d out of range (%d present)", device, ndev);
+	HIP_TRY(hipSetDevice(device));
+	flacamd_decoder *d = new (std::nothrow) flacamd_decoder();
+	if (!d)
+		return fa_fail(FLACAMD_E_NOMEM, "out of host memory");
+	memset(d, 0, sizeof *d);
+	d->device = device;
+	d->channels = channels;
+	d->bps = bits_per_sample;
+	d->max_blocksize = max_blocksize;
+	d->max_frames = max_frames;
+	d->max_input_bytes = max_input_bytes;
+	d->max_streams = max_frames;  // a stream holds at least one frame
+	const uint32_t nb = fa_dec_sync_blocks(max_input_bytes);
+	const size_t groups = (max_frames + 63) / 64;
+#define ALLOC(ptr, bytes) \
+	do { \
+		hipError_t e_ = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 16); \
+		if (e_ != hipSuccess) { \
+			flacamd_decoder_destroy(d); \
+			return fa_fail(FLACAMD_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+		} \
+	} while (0)
+	ALLOC(d->streams, sizeof(FaStream) * d->max_streams);
+	ALLOC(d->block_counts, sizeof(uint32_t) * nb);
+	ALLOC(d->block_offsets, sizeof(uint64_t) * (nb + 1));
+	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
+	ALLOC(d->ncand, 16);
+	ALLOC(d->tmp, sizeof(int32_t) * groups * 64 * channels * max_blocksize);
+	ALLOC(d->result, 32);
+#undef ALLOC
+	uint16_t t16[256], pow16[32];
+	uint8_t t8[256];
+	for (uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i << 8;
+		for (int b = 0; b < 8; b++)
+			c = (c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1);
+		t16[i] = (uint16_t)c;
+		uint32_t e = i;
+		for (int b = 0; b < 8; b++)
+			e = (e & 0x80) ? ((e << 1) ^ 0x07) : (e << 1);
+		t8[i] = (uint8_t)e;
+	}
+	auto mul = [](uint32_t a, uint32_t b) {
+		uint32_t r = 0;
+		for (int i = 0; i < 16; i++) {
+			if (b & 1) r ^= a;
+			b >>= 1;
+			a <<= 1;
+			if (a & 0x10000) a ^= 0x18005;
+		}
+		return r;
+	};
+	uint32_t p = 0x100;
+	for (int j = 0; j < 32; j++) {
+		pow16[j] = (uint16_t)p;
+		p = mul(p, p);
+	}
+	fa_dec_upload_tables(t16, pow16, t8);
+	for (int i = 0; i <= FLACAMD_DEC_STAGES; i++)
+		if (hipEventCreate(&d->ev[i]) != hipSuccess) {
+			flacamd_decoder_destroy(d);
+			return fa_fail(FLACAMD_E_DEVICE, "hipEventCreate failed");
+		}
+	HIP_TRY(hipDeviceSynchronize());
+	*out = d;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_dev, uint64_t flac_bytes, const flacamd_stream_desc *streams_host,
+                                      uint32_t nstreams, void *pcm_out_dev, uint32_t out_sample_bytes, uint64_t out_capacity_wide, void *stream)
+{
+	if (!d || !flac_dev || !streams_host || !pcm_out_dev)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_decode_streams: null argument");
+	if (out_sample_bytes != 2 && out_sample_bytes != 4)
+		return fa_fail(FLACAMD_E_INVALID, "out_sample_bytes must be 2 or 4");
+	if (out_sample_bytes * 8 < d->bps)
+		return fa_fail(FLACAMD_E_INVALID, "%u-byte output samples cannot hold %u bits", out_sample_bytes, d->bps);
+	if (flac_bytes > d->max_input_bytes)
+		return fa_fail(FLACAMD_E_INVALID, "input of %llu bytes exceeds the decoder's capacity", (unsigned long long)flac_bytes);
+	if (nstreams == 0 || nstreams > d->max_streams)
+		return fa_fail(FLACAMD_E_INVALID, "bad stream count %u", nstreams);
+	if ((uintptr_t)flac_dev & 3)
+		return fa_fail(FLACAMD_E_INVALID, "the FLAC buffer must be 4-byte aligned");
+	uint64_t prev_end = 0;
+	for (uint32_t i = 0; i < nstreams; i++) {
+		const flacamd_stream_desc &s = streams_host[i];
+		if (s.byte_offset < prev_end || s.byte_offset + s.byte_length > flac_bytes)
+			return fa_fail(FLACAMD_E_INVALID, "stream %u: byte range out of order or out of bounds", i);
+		prev_end = s.byte_offset + s.byte_length;
+	}
+	HIP_TRY(hipSetDevice(d->device));
+	hipStream_t st = (hipStream_t)stream;
+	static_assert(sizeof(FaStream) == sizeof(flacamd_stream_desc), "stream descriptor layout");
+	HIP_TRY(hipMemcpyAsync(d->streams, streams_host, sizeof(FaStream) * nstreams, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(d->ncand, 0, 16, st));
+	HIP_TRY(hipMemsetAsync(d->result, 0, 32, st));
+	FaDecParams P;
+	P.channels = d->channels;
+	P.bps = d->bps;
+	P.max_blocksize = d->max_blocksize;
+	P.out_sample_bytes = out_sample_bytes;
+	P.nstreams = nstreams;
+	P.max_frames = d->max_frames;
+	P.flac_bytes = flac_bytes;
+	P.out_capacity_wide = out_capacity_wide;
+	const bool prof = d->profiling != 0;
+	int evi = 0;
+#define STAGE_MARK() \
+	do { \
+		if (prof) \
+			HIP_TRY(hipEventRecord(d->ev[evi++], st)); \
+	} while (0)
+	STAGE_MARK();
+	// frames that fail their checks leave zeros, like the reference's zeroed blocks
+	HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, (size_t)out_capacity_wide * d->channels * out_sample_bytes, st));
+	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->block_offsets, d->cands, d->ncand, st);
+	STAGE_MARK();
+	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, st);
+	STAGE_MARK();
+	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, st);
+	STAGE_MARK();
+	fa_dec_launch_output(P, d->streams, d->cands, d->ncand, d->tmp, pcm_out_dev, d->result, st);
+	STAGE_MARK();
+#undef STAGE_MARK
+	if (prof)
+		d->have_times = 1;
+	d->last_stream = st;
+	HIP_TRY(hipGetLastError());
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint64_t *wide_samples, uint32_t *bad_frames)
+{
+	if (!d)
+		return fa_fail(FLACAMD_E_INVALID, "null decoder");
+	HIP_TRY(hipSetDevice(d->device));
+	HIP_TRY(hipStreamSynchronize(d->last_stream));
+	unsigned long long r[3];
+	uint32_t nc[2];
+	HIP_TRY(hipMemcpy(r, d->result, sizeof r, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(nc, d->ncand, sizeof nc, hipMemcpyDeviceToHost));
+	if (frames) *frames = (uint32_t)r[0];
+	if (wide_samples) *wide_samples = r[1];
+	if (bad_frames) *bad_frames = (uint32_t)r[2];
+	if (nc[1])
+		return fa_fail(FLACAMD_E_OVERFLOW, "more frames in the input than the decoder's capacity of %u", d->max_frames);
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decode_streams_host(flacamd_decoder *d, const uint8_t *flac, uint64_t flac_bytes, const flacamd_stream_desc *streams,
+                                           uint32_t nstreams, void *pcm_out, uint32_t out_sample_bytes, uint64_t out_capacity_wide,
+                                           uint32_t *frames, uint64_t *wide_samples, uint32_t *bad_frames)
+{
+	if (!d || !flac || !pcm_out)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_decode_streams_host: null argument");
+	if (flac_bytes > d->max_input_bytes)
+		return fa_fail(FLACAMD_E_INVALID, "input of %llu bytes exceeds the decoder's capacity", (unsigned long long)flac_bytes);
+	HIP_TRY(hipSetDevice(d->device));
+	const size_t out_bytes = (size_t)out_capacity_wide * d->channels * out_sample_bytes;
+	if (!d->stage_in)
+		if (hipMalloc((void **)&d->stage_in, d->max_input_bytes + 8) != hipSuccess)
+			return fa_fail(FLACAMD_E_NOMEM, "staging input: hipMalloc failed");
+	if (d->stage_out_bytes < out_bytes) {
+		(void)hipFree(d->stage_out);
+		d->stage_out = nullptr;
+		d->stage_out_bytes = 0;
+		if (hipMalloc(&d->stage_out, out_bytes ? out_bytes : 16) != hipSuccess)
+			return fa_fail(FLACAMD_E_NOMEM, "staging output: hipMalloc failed");
+		d->stage_out_bytes = out_bytes;
+	}
+	HIP_TRY(hipMemcpy(d->stage_in, flac, flac_bytes, hipMemcpyHostToDevice));
+	int rc = flacamd_decode_streams(d, d->stage_in, flac_bytes, streams, nstreams, d->stage_out, out_sample_bytes, out_capacity_wide, nullptr);
+	if (rc)
+		return rc;
+	rc = flacamd_decoder_result(d, frames, wide_samples, bad_frames);
+	if (rc)
+		return rc;
+	HIP_TRY(hipMemcpy(pcm_out, d->stage_out, out_bytes, hipMemcpyDeviceToHost));
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_set_profiling(flacamd_decoder *d, int on)
+{
+	if (!d)
+		return fa_fail(FLACAMD_E_INVALID, "null decoder");
+	d->profiling = on ? 1 : 0;
+	d->have_times = 0;
+	return FLACAMD_OK;
+}
+
+static const char *kDecStage[FLACAMD_DEC_STAGES] = {"sync", "frames", "crc", "output"};
+extern "C" const char *flacamd_decoder_stage_name(int s) { return (s >= 0 && s < FLACAMD_DEC_STAGES) ? kDecStage[s] : ""; }
+
+extern "C" int flacamd_decoder_stage_ms(flacamd_decoder *d, float ms[FLACAMD_DEC_STAGES])
+{
+	if (!d || !ms)
+		return fa_fail(FLACAMD_E_INVALID, "bad arguments");
+	if (!d->have_times)
+		return fa_fail(FLACAMD_E_INVALID, "no profiled decode has run");
+	HIP_TRY(hipSetDevice(d->device));
+	HIP_TRY(hipEventSynchronize(d->ev[FLACAMD_DEC_STAGES]));
+	for (int i = 0; i < FLACAMD_DEC_STAGES; i++)
+		HIP_TRY(hipEventElapsedTime(&ms[i], d->ev[i], d->ev[i + 1]));
+	return FLACAMD_OK;
+}

@@ -1,0 +1,43 @@
+// Types and launchers of the decoder kernels (dec_kernels.hip).
+#ifndef FLAC_AMD_DEC_KERNELS_H
+#define FLAC_AMD_DEC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "flac_amd_internal.h"
+
+struct FaDecParams {
+	uint32_t channels, bps, max_blocksize, out_sample_bytes;
+	uint32_t nstreams, max_frames;
+	uint64_t flac_bytes;
+	uint64_t out_capacity_wide;
+};
+
+struct FaStream {
+	uint64_t byte_offset, byte_length, sample_offset, total_samples, first_sample;
+};
+
+// A byte position that holds a sync code and a valid frame header.
+struct FaFrameCand {
+	uint64_t pos;        // byte offset of the sync code
+	uint64_t sample;     // number of the frame's first sample, from the header
+	uint64_t end_byte;   // first byte after the frame (after the CRC-16)
+	uint32_t hdr_bytes;
+	uint32_t blocksize;
+	uint32_t assignment;
+	uint32_t stream;
+	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch
+	uint32_t pad;
+};
+
+void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
+uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
+void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
+                        FaFrameCand *cands, uint32_t *ncand, hipStream_t st);
+void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
+                          int32_t *tmp, hipStream_t st);
+void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st);
+void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
+                          void *out, unsigned long long *result, hipStream_t st);
+
+#endif

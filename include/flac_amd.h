@@ -130,6 +130,8 @@ typedef struct {
 	uint64_t byte_length;     /* bytes of frame data */
 	uint64_t sample_offset;   /* where this stream's first wide sample goes in the output */
 	uint64_t total_samples;   /* wide samples expected (0 = unknown: decode what is there) */
+	uint64_t first_sample;    /* sample number, as coded in the frame headers, that lands at
+	                             sample_offset (0 for a stream decoded from its beginning) */
 } flacamd_stream_desc;
 
 /* channels / bits_per_sample / max_blocksize come from STREAMINFO (stream_decoder.c:1423
@@ -146,6 +148,11 @@ int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_dev, uint64_t
                            const flacamd_stream_desc *streams_host, uint32_t nstreams,
                            void *pcm_out_dev, uint32_t out_sample_bytes, uint64_t out_capacity_wide,
                            void *stream);
+/* Same, host buffers in and out; synchronous; fills the three counters of flacamd_decoder_result. */
+int flacamd_decode_streams_host(flacamd_decoder *d, const uint8_t *flac, uint64_t flac_bytes,
+                                const flacamd_stream_desc *streams, uint32_t nstreams, void *pcm_out,
+                                uint32_t out_sample_bytes, uint64_t out_capacity_wide,
+                                uint32_t *frames, uint64_t *wide_samples, uint32_t *bad_frames);
 /* Blocks until the decode finished; reports frames decoded, wide samples written and the number
  * of frames whose CRC-16 or structure was bad (those are zero-filled, stream_decoder.c:2105-2113). */
 int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint64_t *wide_samples,
