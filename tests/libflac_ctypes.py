@@ -26,11 +26,10 @@ class FrameHeader(C.Structure):
 
 def load(path):
     lib = C.CDLL(path)
-    lib.FLAC__stream_encoder_new.restype = C.c_void_p
-    lib.FLAC__stream_decoder_new.restype = C.c_void_p
-    for name in ("FLAC__stream_encoder_delete", "FLAC__stream_decoder_delete"):
-        getattr(lib, name).argtypes = [C.c_void_p]
-        getattr(lib, name).restype = None
+    for kind in ("encoder",) + (("decoder",) if hasattr(lib, "FLAC__stream_decoder_new") else ()):
+        getattr(lib, "FLAC__stream_%s_new" % kind).restype = C.c_void_p
+        getattr(lib, "FLAC__stream_%s_delete" % kind).argtypes = [C.c_void_p]
+        getattr(lib, "FLAC__stream_%s_delete" % kind).restype = None
     return lib
 
 
