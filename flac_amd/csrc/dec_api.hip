@@ -18,7 +18,7 @@
 
 struct flacamd_decoder {
 	int device;
-	uint32_t channels, bps, max_blocksize, max_frames;
+	uint32_t channels, bps, max_blocksize, max_frames, number_scale;
 	uint64_t max_input_bytes;
 	uint32_t max_streams;
 	FaStream *streams;
@@ -85,6 +85,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	d->channels = channels;
 	d->bps = bits_per_sample;
 	d->max_blocksize = max_blocksize;
+	d->number_scale = max_blocksize;
 	d->max_frames = max_frames;
 	d->max_input_bytes = max_input_bytes;
 	d->max_streams = max_frames;  // a stream holds at least one frame
@@ -165,6 +166,8 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 		if (s.byte_offset < prev_end || s.byte_offset + s.byte_length > flac_bytes)
 			return fa_fail(FLACAMD_E_INVALID, "stream %u: byte range out of order or out of bounds", i);
 		prev_end = s.byte_offset + s.byte_length;
+		if (s.first_sample == FLACAMD_FIRST_SAMPLE_AUTO && nstreams != 1)
+			return fa_fail(FLACAMD_E_INVALID, "FLACAMD_FIRST_SAMPLE_AUTO needs a single stream");
 	}
 	HIP_TRY(hipSetDevice(d->device));
 	hipStream_t st = (hipStream_t)stream;
@@ -179,6 +182,8 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.out_sample_bytes = out_sample_bytes;
 	P.nstreams = nstreams;
 	P.max_frames = d->max_frames;
+	P.number_scale = d->number_scale;
+	P.pad = 0;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	const bool prof = d->profiling != 0;
@@ -222,6 +227,37 @@ extern "C" int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint
 	if (bad_frames) *bad_frames = (uint32_t)r[2];
 	if (nc[1])
 		return fa_fail(FLACAMD_E_OVERFLOW, "more frames in the input than the decoder's capacity of %u", d->max_frames);
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_set_frame_number_scale(flacamd_decoder *d, uint32_t samples_per_frame_number)
+{
+	if (!d || samples_per_frame_number == 0)
+		return fa_fail(FLACAMD_E_INVALID, "bad arguments");
+	d->number_scale = samples_per_frame_number;
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_frames(flacamd_decoder *d, flacamd_frame_info *out, uint32_t capacity, uint32_t *count, int *truncated)
+{
+	if (!d || !count || (capacity && !out))
+		return fa_fail(FLACAMD_E_INVALID, "bad arguments");
+	static_assert(sizeof(flacamd_frame_info) == sizeof(FaFrameCand), "frame table layout");
+	HIP_TRY(hipSetDevice(d->device));
+	HIP_TRY(hipStreamSynchronize(d->last_stream));
+	uint32_t nc[2];
+	HIP_TRY(hipMemcpy(nc, d->ncand, sizeof nc, hipMemcpyDeviceToHost));
+	uint32_t n = nc[0];
+	int cut = nc[1] ? 1 : 0;
+	if (n > capacity) {
+		n = capacity;
+		cut = 1;
+	}
+	if (n)
+		HIP_TRY(hipMemcpy(out, d->cands, sizeof(FaFrameCand) * n, hipMemcpyDeviceToHost));
+	*count = n;
+	if (truncated)
+		*truncated = cut;
 	return FLACAMD_OK;
 }
 

@@ -9,6 +9,8 @@
 struct FaDecParams {
 	uint32_t channels, bps, max_blocksize, out_sample_bytes;
 	uint32_t nstreams, max_frames;
+	uint32_t number_scale;   // samples per frame number in fixed-blocksize headers
+	uint32_t pad;
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
 };
@@ -26,7 +28,7 @@ struct FaFrameCand {
 	uint32_t blocksize;
 	uint32_t assignment;
 	uint32_t stream;
-	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch
+	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch, 4 cut off by the end of input
 	uint32_t pad;
 };
 

@@ -152,7 +152,7 @@ __device__ bool parse_frame_header(const uint8_t *d, uint64_t p, const FaDecPara
 	c.stream = (uint32_t)sidx;
 	// a fixed-blocksize stream numbers frames; the sample number follows from the stream's
 	// blocksize (stream_decoder.c:2416-2427)
-	c.sample = variable ? v : v * (uint64_t)P.max_blocksize;
+	c.sample = variable ? v : v * (uint64_t)P.number_scale;
 	c.status = 0;
 	c.end_byte = 0;
 	return true;
@@ -535,7 +535,9 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		if (end_byte * 8 > r.end)
 			r.err = true;
 		cands[j].end_byte = end_byte;
-		cands[j].status = r.err ? 2u : 1u;
+		// a parse that ran off the end of the input is a cut-off frame, not a malformed one
+		const bool cut = r.pos > r.end || end_byte * 8 > r.end;
+		cands[j].status = cut ? 4u : r.err ? 2u : 1u;
 	}
 }
 
@@ -671,9 +673,11 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 		if (cf.status != 1 || i0 >= cf.blocksize)
 			continue;
 		const FaStream st = streams[cf.stream];
-		if (cf.sample < st.first_sample)
+		// FLACAMD_FIRST_SAMPLE_AUTO (single stream): the first header found anchors the output
+		const uint64_t first = st.first_sample == ~0ull ? cands[0].sample : st.first_sample;
+		if (cf.sample < first)
 			continue;
-		const uint64_t rel = cf.sample - st.first_sample + i0;
+		const uint64_t rel = cf.sample - first + i0;
 		uint32_t nvalid = cf.blocksize - i0;
 		if (nvalid > tile_samples)
 			nvalid = tile_samples;

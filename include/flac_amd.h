@@ -131,8 +131,11 @@ typedef struct {
 	uint64_t sample_offset;   /* where this stream's first wide sample goes in the output */
 	uint64_t total_samples;   /* wide samples expected (0 = unknown: decode what is there) */
 	uint64_t first_sample;    /* sample number, as coded in the frame headers, that lands at
-	                             sample_offset (0 for a stream decoded from its beginning) */
+	                             sample_offset (0 for a stream decoded from its beginning);
+	                             FLACAMD_FIRST_SAMPLE_AUTO with a single stream: the number in
+	                             the first frame header found */
 } flacamd_stream_desc;
+#define FLACAMD_FIRST_SAMPLE_AUTO (~(uint64_t)0)
 
 /* channels / bits_per_sample / max_blocksize come from STREAMINFO (stream_decoder.c:1423
  * read_metadata_); all streams of one decoder share them. */
@@ -153,6 +156,27 @@ int flacamd_decode_streams_host(flacamd_decoder *d, const uint8_t *flac, uint64_
                                 const flacamd_stream_desc *streams, uint32_t nstreams, void *pcm_out,
                                 uint32_t out_sample_bytes, uint64_t out_capacity_wide,
                                 uint32_t *frames, uint64_t *wide_samples, uint32_t *bad_frames);
+/* Frame numbers in fixed-blocksize headers count frames; the sample number is that count times the
+ * stream's blocksize (stream_decoder.c:2416-2439).  Defaults to max_blocksize; a caller that knows
+ * better (STREAMINFO min_blocksize, or the first frame's blocksize) sets it here. */
+int flacamd_decoder_set_frame_number_scale(flacamd_decoder *d, uint32_t samples_per_frame_number);
+/* One row per frame header found by the last decode, in byte order: what read_frame_header_ and
+ * read_frame_ (stream_decoder.c:2141,1996) learn about a frame.  status: 1 good, 2 malformed,
+ * 3 CRC-16 mismatch, 4 cut off by the end of the input. */
+typedef struct {
+	uint64_t pos;        /* byte offset of the sync code in the input */
+	uint64_t sample;     /* number of the frame's first sample */
+	uint64_t end_byte;   /* first byte after the frame's CRC-16 */
+	uint32_t hdr_bytes, blocksize;
+	uint32_t assignment; /* FLAC__ChannelAssignment */
+	uint32_t stream;
+	uint32_t status;
+	uint32_t reserved;
+} flacamd_frame_info;
+/* Blocks until the decode finished, then copies up to `capacity` rows.  *truncated is set when
+ * the input held more frame headers than the decoder's max_frames or than `capacity`. */
+int flacamd_decoder_frames(flacamd_decoder *d, flacamd_frame_info *out, uint32_t capacity,
+                           uint32_t *count, int *truncated);
 /* Blocks until the decode finished; reports frames decoded, wide samples written and the number
  * of frames whose CRC-16 or structure was bad (those are zero-filled, stream_decoder.c:2105-2113). */
 int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint64_t *wide_samples,

@@ -147,6 +147,58 @@ extern const unsigned FLAC__STREAM_SYNC;
 extern const unsigned FLAC__STREAM_SYNC_LEN;
 extern const FLAC__uint64 FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER;
 
+/* bit-field widths, masks and name tables (src/libFLAC/format.c:66-211) */
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_MIN_BLOCK_SIZE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_MAX_BLOCK_SIZE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_MIN_FRAME_SIZE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_MAX_FRAME_SIZE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_SAMPLE_RATE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_CHANNELS_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_BITS_PER_SAMPLE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_TOTAL_SAMPLES_LEN;
+extern const unsigned FLAC__STREAM_METADATA_STREAMINFO_MD5SUM_LEN;
+extern const unsigned FLAC__STREAM_METADATA_APPLICATION_ID_LEN;
+extern const unsigned FLAC__STREAM_METADATA_SEEKPOINT_SAMPLE_NUMBER_LEN;
+extern const unsigned FLAC__STREAM_METADATA_SEEKPOINT_STREAM_OFFSET_LEN;
+extern const unsigned FLAC__STREAM_METADATA_SEEKPOINT_FRAME_SAMPLES_LEN;
+extern const unsigned FLAC__STREAM_METADATA_VORBIS_COMMENT_ENTRY_LENGTH_LEN;
+extern const unsigned FLAC__STREAM_METADATA_VORBIS_COMMENT_NUM_COMMENTS_LEN;
+extern const unsigned FLAC__STREAM_METADATA_IS_LAST_LEN;
+extern const unsigned FLAC__STREAM_METADATA_TYPE_LEN;
+extern const unsigned FLAC__STREAM_METADATA_LENGTH_LEN;
+extern const unsigned FLAC__FRAME_HEADER_SYNC;
+extern const unsigned FLAC__FRAME_HEADER_SYNC_LEN;
+extern const unsigned FLAC__FRAME_HEADER_RESERVED_LEN;
+extern const unsigned FLAC__FRAME_HEADER_BLOCKING_STRATEGY_LEN;
+extern const unsigned FLAC__FRAME_HEADER_BLOCK_SIZE_LEN;
+extern const unsigned FLAC__FRAME_HEADER_SAMPLE_RATE_LEN;
+extern const unsigned FLAC__FRAME_HEADER_CHANNEL_ASSIGNMENT_LEN;
+extern const unsigned FLAC__FRAME_HEADER_BITS_PER_SAMPLE_LEN;
+extern const unsigned FLAC__FRAME_HEADER_ZERO_PAD_LEN;
+extern const unsigned FLAC__FRAME_HEADER_CRC_LEN;
+extern const unsigned FLAC__FRAME_FOOTER_CRC_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_TYPE_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_ORDER_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_PARAMETER_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2_PARAMETER_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_RAW_LEN;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE_ESCAPE_PARAMETER;
+extern const unsigned FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2_ESCAPE_PARAMETER;
+extern const unsigned FLAC__SUBFRAME_LPC_QLP_COEFF_PRECISION_LEN;
+extern const unsigned FLAC__SUBFRAME_LPC_QLP_SHIFT_LEN;
+extern const unsigned FLAC__SUBFRAME_ZERO_PAD_LEN;
+extern const unsigned FLAC__SUBFRAME_TYPE_LEN;
+extern const unsigned FLAC__SUBFRAME_WASTED_BITS_FLAG_LEN;
+extern const unsigned FLAC__SUBFRAME_TYPE_CONSTANT_BYTE_ALIGNED_MASK;
+extern const unsigned FLAC__SUBFRAME_TYPE_VERBATIM_BYTE_ALIGNED_MASK;
+extern const unsigned FLAC__SUBFRAME_TYPE_FIXED_BYTE_ALIGNED_MASK;
+extern const unsigned FLAC__SUBFRAME_TYPE_LPC_BYTE_ALIGNED_MASK;
+extern const char *const FLAC__EntropyCodingMethodTypeString[];
+extern const char *const FLAC__SubframeTypeString[];
+extern const char *const FLAC__ChannelAssignmentString[];
+extern const char *const FLAC__FrameNumberTypeString[];
+extern const char *const FLAC__MetadataTypeString[];
+
 /* src/libFLAC/format.c:213-314 */
 FLAC__bool FLAC__format_sample_rate_is_valid(unsigned sample_rate);
 FLAC__bool FLAC__format_blocksize_is_subset(unsigned blocksize, unsigned sample_rate);

@@ -232,7 +232,83 @@ def kats(ref):
     return out
 
 
+# Damaged and oddly framed streams for the decoder: what the reference's stream decoder reports
+# (error callbacks, the blocks it hands to the write callback, return values, final state).
+DAMAGE = [
+    # (name, golden case, edit)
+    ("flip_mid_frame", "s16_l5", ("xor", 0.5, 0x55)),
+    ("flip_early", "s16_l5", ("xor", 0.1, 0x01)),
+    ("flip_24bit", "s24_l8", ("xor", 0.6, 0x80)),
+    ("flip_header", "s16_l2_bs1152x", ("xor_frame_byte", 1, 2, 0xf0)),   # frame 1, header byte 2
+    ("flip_crc16", "s16_l2_bs1152x", ("xor_frame_byte", 2, -1, 0xff)),   # frame 2, last CRC byte
+    ("truncated", "s16_l5", ("truncate", 0.7)),
+    ("garbage_prefix", "m16_l2", ("prefix", 333)),
+    ("garbage_suffix", "m16_l2", ("suffix", 500)),
+    ("id3v2_prefix", "m16_l2", ("id3", 200)),
+    ("no_metadata", "s16_l8", ("strip_meta",)),
+    ("frames_from_middle", "s16_l2_bs1152x", ("from_frame", 1)),
+    ("dropped_frame", "s16_l2_bs1152x", ("drop_frame", 1)),
+]
+
+
+def apply_damage(meta, frames, edit):
+    kind = edit[0]
+    stream = bytearray(meta + b"".join(frames))
+    if kind == "xor":
+        off = len(meta) + int((len(stream) - len(meta)) * edit[1])
+        stream[off] ^= edit[2]
+    elif kind == "xor_frame_byte":
+        start = len(meta) + sum(len(f) for f in frames[:edit[1]])
+        idx = edit[2] if edit[2] >= 0 else len(frames[edit[1]]) + edit[2]
+        stream[start + idx] ^= edit[3]
+    elif kind == "truncate":
+        del stream[len(meta) + int((len(stream) - len(meta)) * edit[1]):]
+    elif kind == "prefix":
+        rng = np.random.default_rng(5)
+        junk = rng.integers(0, 255, size=edit[1], dtype=np.uint8).tobytes().replace(b"\xff", b"\x00").replace(b"f", b"g").replace(b"I", b"J")
+        stream = bytearray(junk) + stream
+    elif kind == "suffix":
+        rng = np.random.default_rng(6)
+        stream += rng.integers(0, 255, size=edit[1], dtype=np.uint8).tobytes()
+    elif kind == "id3":
+        n = edit[1]
+        tag = b"ID3\x03\x00\x00" + bytes([(n >> 21) & 0x7f, (n >> 14) & 0x7f, (n >> 7) & 0x7f, n & 0x7f]) + b"\x41" * n
+        stream = bytearray(tag) + stream
+    elif kind == "strip_meta":
+        stream = bytearray(b"".join(frames))
+    elif kind == "from_frame":
+        stream = bytearray(b"".join(frames[edit[1]:]))
+    elif kind == "drop_frame":
+        stream = bytearray(meta + b"".join(f for i, f in enumerate(frames) if i != edit[1]))
+    return bytes(stream)
+
+
+def damaged_vectors(ref):
+    import golden_util
+    cases = {c["name"]: c for c in golden_util.load_index()}
+    out = []
+    for name, cname, edit in DAMAGE:
+        _pcm, meta, frames = golden_util.load_case(cases[cname])
+        stream = apply_damage(meta, frames, edit)
+        sd = L.StreamDecoder(ref, stream, md5_check=True)
+        assert sd.init_status == 0
+        ok = bool(sd.call("process_until_end_of_stream"))
+        state = sd.state()
+        fin = bool(sd.call("finish"))
+        sd.close()
+        out.append(dict(name=name, case=cname, edit=list(edit), stream_sha256=hashlib.sha256(stream).hexdigest(),
+                        process_ok=ok, state=state, finish_ok=fin, errors=sd.errors,
+                        blocks=[[n, int(b.shape[0]), hashlib.sha256(np.ascontiguousarray(b).tobytes()).hexdigest()] for n, b in sd.blocks]))
+        print("%-20s ok=%d state=%d fin=%d errors=%s blocks=%d" % (name, ok, state, fin, sd.errors, len(sd.blocks)))
+    return out
+
+
 def main():
+    if "--damaged-only" in sys.argv:
+        ref = L.load(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so"))
+        with open(os.path.join(GOLD, "damaged.json"), "w") as f:
+            json.dump(damaged_vectors(ref), f, indent=1)
+        return
     ref_path = os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so")
     ref = L.load(ref_path)
     os.makedirs(GOLD, exist_ok=True)
@@ -264,6 +340,8 @@ def main():
         json.dump(index, f, indent=1)
     with open(os.path.join(GOLD, "kats.json"), "w") as f:
         json.dump(kats(ref), f, indent=1)
+    with open(os.path.join(GOLD, "damaged.json"), "w") as f:
+        json.dump(damaged_vectors(ref), f, indent=1)
     print("total fixture bytes: %d" % total)
 
 

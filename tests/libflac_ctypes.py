@@ -121,49 +121,122 @@ def encode(lib, pcm, bits_per_sample, sample_rate, level=None, blocksize=0, sett
     return bytes(stream[:meta_len]), frames, good, writes
 
 
-def decode(lib, stream_bytes, md5_check=True):
-    """Decode a whole FLAC stream through the stream decoder API.
+DEC_SEEK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p)
+DEC_TELL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+DEC_LENGTH_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p)
+DEC_EOF_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+DEC_METADATA_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
-    Returns (pcm int32 (n, channels), list of error codes, finish_ok).
+
+class MetadataHead(C.Structure):
+    """Leading fields of FLAC__StreamMetadata (include/FLAC/format.h:811)."""
+    _fields_ = [("type", C.c_int), ("is_last", C.c_int), ("length", C.c_uint)]
+
+
+class StreamDecoder:
+    """A stream decoder over an in-memory FLAC stream, with every callback recorded.
+
+    blocks: [(first_sample, int32 array (blocksize, channels))]; errors: [status];
+    metadata: [(type, is_last, length)].  max_read caps what one read callback returns.
     """
-    dec = C.c_void_p(lib.FLAC__stream_decoder_new())
-    if md5_check:
-        lib.FLAC__stream_decoder_set_md5_checking(dec, C.c_int(1))
-    data = bytes(stream_bytes)
-    state = {"pos": 0}
-    blocks = []
-    errors = []
 
-    def on_read(_d, buf, pbytes, _c):
+    def __init__(self, lib, stream_bytes, md5_check=True, seekable=False, max_read=None, respond_all=False):
+        self.lib = lib
+        self.data = bytes(stream_bytes)
+        self.pos = 0
+        self.blocks, self.errors, self.metadata = [], [], []
+        self.max_read = max_read
+        self.abort_writes = False
+        lib.FLAC__stream_decoder_get_total_samples.restype = C.c_uint64
+        lib.FLAC__stream_decoder_get_resolved_state_string.restype = C.c_char_p
+        self.dec = C.c_void_p(lib.FLAC__stream_decoder_new())
+        if md5_check:
+            assert lib.FLAC__stream_decoder_set_md5_checking(self.dec, C.c_int(1))
+        if respond_all:
+            assert lib.FLAC__stream_decoder_set_metadata_respond_all(self.dec)
+        self._cbs = (DEC_READ_CB(self._read), DEC_SEEK_CB(self._seek), DEC_TELL_CB(self._tell), DEC_LENGTH_CB(self._length),
+                     DEC_EOF_CB(self._eof), DEC_WRITE_CB(self._write), DEC_METADATA_CB(self._meta), DEC_ERROR_CB(self._error))
+        r, s_, t, l_, e, w, m, err = self._cbs
+        if seekable:
+            self.init_status = lib.FLAC__stream_decoder_init_stream(self.dec, r, s_, t, l_, e, w, m, err, None)
+        else:
+            self.init_status = lib.FLAC__stream_decoder_init_stream(self.dec, r, None, None, None, None, w, m, err, None)
+
+    def _read(self, _d, buf, pbytes, _c):
         want = pbytes[0]
-        take = min(want, len(data) - state["pos"])
+        if self.max_read:
+            want = min(want, self.max_read)
+        take = min(want, len(self.data) - self.pos)
         if take == 0:
             pbytes[0] = 0
             return 1  # END_OF_STREAM
-        C.memmove(buf, data[state["pos"]:state["pos"] + take], take)
-        state["pos"] += take
+        C.memmove(buf, self.data[self.pos:self.pos + take], take)
+        self.pos += take
         pbytes[0] = take
         return 0
 
-    def on_write(_d, frame, buffers, _c):
+    def _seek(self, _d, off, _c):
+        if off > len(self.data):
+            return 1
+        self.pos = off
+        return 0
+
+    def _tell(self, _d, poff, _c):
+        poff[0] = self.pos
+        return 0
+
+    def _length(self, _d, plen, _c):
+        plen[0] = len(self.data)
+        return 0
+
+    def _eof(self, _d, _c):
+        return 1 if self.pos >= len(self.data) else 0
+
+    def _write(self, _d, frame, buffers, _c):
         hdr = C.cast(frame, C.POINTER(FrameHeader)).contents
         bs, ch = hdr.blocksize, hdr.channels
         blk = np.empty((bs, ch), dtype=np.int32)
         for c in range(ch):
             blk[:, c] = np.ctypeslib.as_array(buffers[c], shape=(bs,))
-        blocks.append(blk)
-        return 0
+        self.blocks.append((int(hdr.number), blk))
+        self.last_header = (hdr.blocksize, hdr.sample_rate, hdr.channels, hdr.channel_assignment, hdr.bits_per_sample,
+                            hdr.number_type, int(hdr.number), hdr.crc)
+        return 1 if self.abort_writes else 0
 
-    def on_error(_d, status, _c):
-        errors.append(status)
+    def _meta(self, _d, block, _c):
+        h = C.cast(block, C.POINTER(MetadataHead)).contents
+        self.metadata.append((h.type, h.is_last, h.length))
 
-    rcb, wcb, ecb = DEC_READ_CB(on_read), DEC_WRITE_CB(on_write), DEC_ERROR_CB(on_error)
-    st = lib.FLAC__stream_decoder_init_stream(dec, rcb, None, None, None, None, wcb, None, ecb, None)
-    if st != 0:
-        lib.FLAC__stream_decoder_delete(dec)
-        raise RuntimeError("decoder init_stream failed with status %d" % st)
-    ok = bool(lib.FLAC__stream_decoder_process_until_end_of_stream(dec))
-    fin = bool(lib.FLAC__stream_decoder_finish(dec))
-    lib.FLAC__stream_decoder_delete(dec)
-    pcm = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, 1), dtype=np.int32)
-    return pcm, errors, ok and fin
+    def _error(self, _d, status, _c):
+        self.errors.append(status)
+
+    def call(self, name, *args):
+        return getattr(self.lib, "FLAC__stream_decoder_" + name)(self.dec, *args)
+
+    def state(self):
+        return self.call("get_state")
+
+    def pcm(self):
+        if not self.blocks:
+            return np.zeros((0, 1), dtype=np.int32)
+        return np.concatenate([b for _n, b in self.blocks], axis=0)
+
+    def close(self):
+        if self.dec:
+            self.lib.FLAC__stream_decoder_delete(self.dec)
+            self.dec = None
+
+
+def decode(lib, stream_bytes, md5_check=True, max_read=None):
+    """Decode a whole FLAC stream through the stream decoder API.
+
+    Returns (pcm int32 (n, channels), list of error codes, finish_ok).
+    """
+    sd = StreamDecoder(lib, stream_bytes, md5_check=md5_check, max_read=max_read)
+    if sd.init_status != 0:
+        sd.close()
+        raise RuntimeError("decoder init_stream failed with status %d" % sd.init_status)
+    ok = bool(sd.call("process_until_end_of_stream"))
+    fin = bool(sd.call("finish"))
+    sd.close()
+    return sd.pcm(), sd.errors, ok and fin

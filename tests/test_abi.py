@@ -17,8 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b((?:flacamd|FLAC__)\w+)\s*\(", text))
+    # a name followed by "(" is a function, unless the parenthesis opens a function-pointer typedef
+    names = set(re.findall(r"\b((?:flacamd|FLAC__)\w+)\s*\((?!\s*\*)", text))
     return sorted(n for n in names if not n.isupper())
+
+
+def declared_data(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"^extern\s+const\s[^;(]*?\b(FLAC__\w+)\s*(?:\[[^\]]*\])?\s*;", text, flags=re.M)))
 
 
 def test_every_declared_symbol_is_exported():
@@ -31,7 +38,13 @@ def test_every_declared_symbol_is_exported():
         for name in declared_functions(h):
             if not hasattr(lib, name):
                 missing.append("%s:%s" % (h, name))
+        for name in declared_data(h):
+            try:
+                C.c_int.in_dll(lib, name)
+            except ValueError:
+                missing.append("%s:%s (data)" % (h, name))
     assert not missing, missing
+    assert len(declared_functions("flac_amd_stream.h")) > 90 and len(declared_data("flac_amd_stream.h")) > 60
 
 
 def test_presets_resolve_like_the_reference():
