@@ -58,7 +58,7 @@ def _cpu_worker(args):
     return dt, sum(len(f) for f in frames), pcm.shape[0] * CHANNELS
 
 
-def cpu_baseline(seconds=60.0):
+def cpu_baseline(seconds=SECONDS):
     import multiprocessing as mp
     kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so")) else "port"
     try:
@@ -116,7 +116,10 @@ def main():
     params = flac_amd.preset(LEVEL, CHANNELS, BPS, RATE)
     bs = params.blocksize
     nframes = (wide + bs - 1) // bs
-    first_frame = rank * nframes
+    from flac_amd import shard
+    # weak scaling: the job is one stream of world x nframes frames, split into contiguous ranges
+    first_frame, owned = shard.frame_range(nframes * world, world, rank)
+    assert owned == nframes
     pcm_dev = torch.from_numpy(pcm32.astype(np.int16)).to(dev)
     enc = flac_amd.Encoder(params, device=local_rank, max_frames=nframes)
     out_cap = enc.max_output_bytes(nframes)

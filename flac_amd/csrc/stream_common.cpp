@@ -140,6 +140,12 @@ struct Bytes {
 };
 }  // namespace
 
+int fa_stream_device(void)
+{
+	const char *env = getenv("FLAC_AMD_DEVICE");
+	return env ? atoi(env) : 0;
+}
+
 void fa_serialize_metadata(const FLAC__StreamMetadata *m, std::vector<uint8_t> &out)
 {
 	Bytes w{out};

@@ -951,10 +951,7 @@ bool ensure_device(FLAC__StreamDecoder *d)
 	if (q->batch_bytes < 4 * worst_frame)
 		q->batch_bytes = 4 * worst_frame;
 	q->out_cap_wide = (uint64_t)frames * bs;
-	int device = 0;
-	if (const char *env = getenv("FLAC_AMD_DEVICE"))
-		device = atoi(env);
-	if (flacamd_decoder_create(ch, bps, bs, device, q->batch_bytes, q->max_frames, &q->dev) != FLACAMD_OK)
+	if (flacamd_decoder_create(ch, bps, bs, fa_stream_device(), q->batch_bytes, q->max_frames, &q->dev) != FLACAMD_OK)
 		return device_fail(d, "cannot create the device decoder");
 	(void)flacamd_decoder_set_frame_number_scale(q->dev, scale);
 	const size_t out_bytes = (size_t)q->out_cap_wide * ch * sizeof(FLAC__int32);
@@ -1057,6 +1054,7 @@ bool start_batch(FLAC__StreamDecoder *d)
 	q->batch_active = true;
 	if (!q->dev || q->batch_len < 6)
 		return true;  // no frame header anywhere in the buffer
+	(void)hipSetDevice(fa_stream_device());
 	if (hipMemcpy(q->d_in, q->in, q->batch_len, hipMemcpyHostToDevice) != hipSuccess) {
 		fprintf(stderr, "flac_amd: copy to the device failed\n");
 		d->protected_->state = FLAC__STREAM_DECODER_ABORTED;

@@ -559,14 +559,14 @@ FLAC__StreamEncoderInitStatus init_stream_internal(FLAC__StreamEncoder *e, FLAC_
 		if (bf < 1) bf = 1;
 		q->batch_frames = (unsigned)bf;
 	}
-	int rc = flacamd_encoder_create(&ep, 0, q->batch_frames + 1, &q->dev);
+	int rc = flacamd_encoder_create(&ep, fa_stream_device(), q->batch_frames + 1, &q->dev);
 	if (rc != FLACAMD_OK) {
 		p->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
 		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	}
 	if (p->verify) {
 		const uint64_t max_in = flacamd_encoder_max_output_bytes(q->dev, q->batch_frames + 1);
-		rc = flacamd_decoder_create(p->channels, p->bits_per_sample, p->blocksize, 0, max_in, q->batch_frames + 8, &q->verify_dec);
+		rc = flacamd_decoder_create(p->channels, p->bits_per_sample, p->blocksize, fa_stream_device(), max_in, q->batch_frames + 8, &q->verify_dec);
 		if (rc != FLACAMD_OK) {
 			p->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
 			return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;

@@ -303,7 +303,38 @@ def damaged_vectors(ref):
     return out
 
 
+# Caller-supplied metadata blocks: prologue order, the library's vendor string, seek-point fill-in.
+METADATA_CASES = [
+    ("seektable_fill", "s16_l5", [("seektable", [0, 4096, 5000, 12000, 13499, 20000, L.PLACEHOLDER, L.PLACEHOLDER]), ("padding", 100)]),
+    ("comments_app", "s16_l2_bs1152x", [("application", b"tEsT", bytes(range(10))), ("vorbis_comment", [b"TITLE=x", b"ARTIST=somebody"]), ("padding", 0)]),
+    ("seektable_small_blocks", "s16_l5_bs256", [("padding", 7), ("seektable", [1, 255, 256, 257, 600, 1023])]),
+]
+
+
+def metadata_vectors(ref):
+    import golden_util
+    cases = {c["name"]: c for c in golden_util.load_index()}
+    out = []
+    for name, cname, specs in METADATA_CASES:
+        cs = cases[cname]
+        pcm, _meta, frames = golden_util.load_case(cs)
+        meta, got_frames, ok, writes = L.encode(ref, pcm, cs["bps"], cs["rate"], level=cs["level"], blocksize=cs["blocksize"],
+                                                settings=cs["settings"], seekable=True, metadata=specs)
+        assert ok and got_frames == frames, name
+        out.append(dict(name=name, case=cname,
+                        specs=[[s[0]] + [x.hex() if isinstance(x, bytes) else ([y.hex() if isinstance(y, bytes) else y for y in x] if isinstance(x, list) else x)
+                                         for x in s[1:]] for s in specs],
+                        meta=meta.hex(), first_writes=[len(d) for d, smp, _f in writes if smp == 0]))
+        print("%-24s prologue=%d bytes, writes=%s" % (name, len(meta), out[-1]["first_writes"]))
+    return out
+
+
 def main():
+    if "--metadata-only" in sys.argv:
+        ref = L.load(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so"))
+        with open(os.path.join(GOLD, "metadata.json"), "w") as f:
+            json.dump(metadata_vectors(ref), f, indent=1)
+        return
     if "--damaged-only" in sys.argv:
         ref = L.load(os.path.join(ROOT, "oracle", "_ref", "libFLAC_ref.so"))
         with open(os.path.join(GOLD, "damaged.json"), "w") as f:
@@ -342,6 +373,8 @@ def main():
         json.dump(kats(ref), f, indent=1)
     with open(os.path.join(GOLD, "damaged.json"), "w") as f:
         json.dump(damaged_vectors(ref), f, indent=1)
+    with open(os.path.join(GOLD, "metadata.json"), "w") as f:
+        json.dump(metadata_vectors(ref), f, indent=1)
     print("total fixture bytes: %d" % total)
 
 

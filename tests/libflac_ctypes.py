@@ -33,8 +33,96 @@ def load(path):
     return lib
 
 
+# ---- FLAC__StreamMetadata (include/FLAC/format.h:478-846), as far as the tests build blocks ----
+class SeekPoint(C.Structure):
+    _fields_ = [("sample_number", C.c_uint64), ("stream_offset", C.c_uint64), ("frame_samples", C.c_uint)]
+
+
+class SeekTable(C.Structure):
+    _fields_ = [("num_points", C.c_uint), ("points", C.POINTER(SeekPoint))]
+
+
+class VCEntry(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("entry", C.POINTER(C.c_ubyte))]
+
+
+class VorbisComment(C.Structure):
+    _fields_ = [("vendor_string", VCEntry), ("num_comments", C.c_uint32), ("comments", C.POINTER(VCEntry))]
+
+
+class Application(C.Structure):
+    _fields_ = [("id", C.c_ubyte * 4), ("data", C.POINTER(C.c_ubyte))]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("min_blocksize", C.c_uint), ("max_blocksize", C.c_uint), ("min_framesize", C.c_uint),
+                ("max_framesize", C.c_uint), ("sample_rate", C.c_uint), ("channels", C.c_uint),
+                ("bits_per_sample", C.c_uint), ("total_samples", C.c_uint64), ("md5sum", C.c_ubyte * 16)]
+
+
+class MetadataBody(C.Union):
+    _fields_ = [("stream_info", StreamInfo), ("application", Application), ("seek_table", SeekTable),
+                ("vorbis_comment", VorbisComment), ("raw", C.c_ubyte * 192)]
+
+
+class StreamMetadata(C.Structure):
+    _fields_ = [("type", C.c_int), ("is_last", C.c_int), ("length", C.c_uint), ("data", MetadataBody)]
+
+
+PLACEHOLDER = 0xFFFFFFFFFFFFFFFF
+
+
+def _bytes_ptr(b, keep):
+    buf = (C.c_ubyte * max(1, len(b)))(*b)
+    keep.append(buf)
+    return C.cast(buf, C.POINTER(C.c_ubyte))
+
+
+def build_metadata(specs):
+    """specs: list of ("padding", n) | ("seektable", [sample numbers]) | ("application", id4, data) |
+    ("vorbis_comment", [b"K=V", ...]).  Returns (FLAC__StreamMetadata*[] array, count, keepalive)."""
+    keep, blocks = [], []
+    for spec in specs:
+        m = StreamMetadata()
+        kind = spec[0]
+        if kind == "padding":
+            m.type, m.length = 1, spec[1]
+        elif kind == "seektable":
+            pts = (SeekPoint * max(1, len(spec[1])))()
+            for i, sn in enumerate(spec[1]):
+                pts[i].sample_number, pts[i].stream_offset, pts[i].frame_samples = sn, 0, 0
+            keep.append(pts)
+            m.type, m.length = 3, 18 * len(spec[1])
+            m.data.seek_table.num_points = len(spec[1])
+            m.data.seek_table.points = C.cast(pts, C.POINTER(SeekPoint))
+        elif kind == "application":
+            m.type, m.length = 2, 4 + len(spec[2])
+            for i in range(4):
+                m.data.application.id[i] = spec[1][i]
+            m.data.application.data = _bytes_ptr(spec[2], keep)
+        elif kind == "vorbis_comment":
+            ents = (VCEntry * max(1, len(spec[1])))()
+            total = 4 + 4
+            for i, kv in enumerate(spec[1]):
+                ents[i].length = len(kv)
+                ents[i].entry = _bytes_ptr(kv, keep)
+                total += 4 + len(kv)
+            keep.append(ents)
+            m.type, m.length = 4, total
+            m.data.vorbis_comment.vendor_string.length = 0
+            m.data.vorbis_comment.vendor_string.entry = None
+            m.data.vorbis_comment.num_comments = len(spec[1])
+            m.data.vorbis_comment.comments = C.cast(ents, C.POINTER(VCEntry))
+        else:
+            raise ValueError(kind)
+        blocks.append(m)
+    arr = (C.POINTER(StreamMetadata) * max(1, len(blocks)))(*[C.pointer(b) for b in blocks])
+    keep.extend(blocks)
+    return arr, len(blocks), keep
+
+
 def encode(lib, pcm, bits_per_sample, sample_rate, level=None, blocksize=0, settings=None,
-           chunk=None, planar=False, seekable=False, total_samples_estimate=0):
+           chunk=None, planar=False, seekable=False, total_samples_estimate=0, metadata=None):
     """Encode interleaved int32 pcm (n, channels) through the stream API.
 
     Returns (metadata_bytes, [frame_bytes, ...], final_state_ok, writes) where writes is the raw
@@ -64,6 +152,10 @@ def encode(lib, pcm, bits_per_sample, sample_rate, level=None, blocksize=0, sett
             ok &= bool(fn(enc, C.c_int(1 if val else 0)))
         else:
             ok &= bool(fn(enc, u(int(val))))
+    keepalive = None
+    if metadata:
+        arr, count, keepalive = build_metadata(metadata)
+        ok &= bool(lib.FLAC__stream_encoder_set_metadata(enc, arr, u(count)))
     assert ok, "a setter failed"
 
     stream = bytearray()

@@ -79,6 +79,25 @@ def test_verify_mode(lib):
     assert ok and got_frames == frames and got_meta == meta
 
 
+def test_caller_metadata_and_seektable_fill(lib):
+    """set_metadata blocks: prologue order, vendor string, seek points filled in at finish()."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gen_golden
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metadata.json")) as f:
+        want = {v["name"]: v for v in json.load(f)}
+    by_name = {c["name"]: c for c in CASES}
+    for name, cname, specs in gen_golden.METADATA_CASES:
+        cs = by_name[cname]
+        pcm, _meta, frames = golden_util.load_case(cs)
+        meta, got_frames, ok, writes = L.encode(lib, pcm, cs["bps"], cs["rate"], level=cs["level"], blocksize=cs["blocksize"],
+                                                settings=cs["settings"], seekable=True, metadata=specs)
+        assert ok and got_frames == frames, name
+        assert meta.hex() == want[name]["meta"], name
+        assert [len(d) for d, smp, _f in writes if smp == 0] == want[name]["first_writes"], name
+
+
 def test_getters_and_state(lib):
     u = C.c_uint
     enc = C.c_void_p(lib.FLAC__stream_encoder_new())

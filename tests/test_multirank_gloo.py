@@ -1,0 +1,89 @@
+"""Two-process (gloo, CPU) test of the multi-GPU sharding scheme.
+
+Each rank takes its contiguous range of frames (flac_amd.shard.frame_range), encodes it with the
+CPU oracle numbered from the range's first frame, learns its byte offset from the all-gather of byte
+totals (flac_amd.shard.stream_offsets) and writes its bytes there.  The assembled stream must equal
+the golden bytes the reference wrote for the whole signal in one go: the N>1 path moves no sample
+data between ranks and still produces the reference's stream.  On GPUs the same two functions run
+over RCCL with the HIP encoder in place of the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import golden_util
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, case_name, out_path):
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    from flac_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = next(c for c in golden_util.load_index() if c["name"] == case_name)
+        pcm, _meta, _frames = golden_util.load_case(case)
+        p = O.preset(*golden_util.preset_args(case), **golden_util.field_overrides(case))
+        align = shard.loose_mid_side_period(case["rate"], p.blocksize) if p.loose_mid_side_stereo else 1
+        first, s0, n = shard.sample_range(pcm.shape[0], p.blocksize, world, rank, align)
+        frames = O.encode_frames(p, pcm[s0:s0 + n], first_frame=first)[0] if n else []
+        blob = b"".join(frames)
+        offset, total, sizes = shard.stream_offsets(len(blob))
+        assert len(sizes) == world and sizes[rank] == len(blob)
+        if rank == 0:
+            with open(out_path, "wb") as f:
+                f.truncate(total)
+        dist.barrier()
+        with open(out_path, "r+b") as f:
+            f.seek(offset)
+            f.write(blob)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name", ["s16_l8", "s16_l1_loose", "s16_l5_bs256"])
+def test_two_ranks_assemble_the_reference_stream(tmp_path, case_name):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "stream.bin")
+    mp.spawn(worker, args=(2, free_port(), case_name, out), nprocs=2, join=True)
+    case = next(c for c in golden_util.load_index() if c["name"] == case_name)
+    _pcm, _meta, frames = golden_util.load_case(case)
+    assert open(out, "rb").read() == b"".join(frames)
+
+
+def test_frame_ranges_cover_and_align():
+    from flac_amd import shard
+    for total in (0, 1, 5, 6460, 6461, 51680):
+        for world in (1, 2, 3, 8):
+            for align in (1, 4, 15):
+                got = [shard.frame_range(total, world, r, align) for r in range(world)]
+                pos = 0
+                for first, count in got:
+                    if count:
+                        assert first == pos and first % align == 0
+                        pos = first + count
+                assert pos == total
+                counts = [c for _f, c in got]
+                assert max(counts) - min(counts) < 2 * align
+    assert shard.loose_mid_side_period(44100, 1152) == 15
+    assert shard.loose_mid_side_period(44100, 4096) == 4
+    assert shard.loose_mid_side_period(8000, 65535) == 1
+    with pytest.raises(ValueError):
+        shard.frame_range(10, 2, 2)
+
+
+def test_stream_offsets_single_process():
+    from flac_amd import shard
+    assert shard.stream_offsets(123) == (0, 123, [123])
