@@ -306,6 +306,8 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	B.first_frame = first_frame;
 	B.sample_bytes = sample_bytes;
 	B.loose_carry = loose_state ? *loose_state : 0;
+	B.pairs = (sample_bytes == 2 && P.channels == 2 && ((uintptr_t)pcm_dev & 3) == 0) ? 1u : 0u;
+	B.pad = 0;
 	uint32_t *fb = frame_bytes_dev ? frame_bytes_dev : e->frame_bytes;
 	uint64_t *fo = frame_offsets_dev ? frame_offsets_dev : e->offsets;
 	const bool prof = e->profiling != 0;

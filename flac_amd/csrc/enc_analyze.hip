@@ -1,0 +1,544 @@
+// FLAC frame encoder kernels for gfx950 (MI355X), part 1: signal statistics, autocorrelation,
+// LPC analysis, channel decision, frame offsets and compaction.
+//
+// One batch = F consecutive frames of one stream.  Work decomposition:
+//   k_analyze   grid F*S  (S = input channels [+ mid + side])   wasted bits, fixed-predictor sums
+//   k_autoc     grid ceil(F*S*A / tasks-per-block)              windowed autocorrelation, exact order
+//   k_lpc       lane per (frame, signal)                         Levinson-Durbin, order guess, quantise
+//   k_search    grid F*S             (enc_search.hip)            residual + Rice partition search
+//   k_decide    lane per frame                                   channel assignment
+//   k_pack      grid F               (enc_pack.hip)              bit packing into frame slots, CRCs
+//   k_scan      one block                                        frame byte offsets
+//   k_compact   grid F                                           slots -> contiguous stream bytes
+//
+// Arithmetic follows the reference (FLAC 1.2.1) operation for operation where rounding or
+// wraparound is observable; each kernel says which reference function it stands in for.
+// Build with -ffp-contract=off: the reference's float/double expressions are not fused.
+#include <hip/hip_runtime.h>
+
+#include "enc_common.h"
+#include "enc_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_analyze: get_wasted_bits_ (stream_encoder.c:4108) + FLAC__fixed_compute_best_predictor[_wide]
+// (fixed.c:224,282) + the all-samples-equal test of process_subframe_ (:3210-3227)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
+{
+	const uint32_t task = blockIdx.x;
+	const uint32_t f = task / P.nsignals, s = task % P.nsignals;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);
+	const uint64_t frame_start = (uint64_t)f * P.blocksize;
+	__shared__ uint32_t sh_or[4], sh_ne[4];
+	__shared__ uint64_t sh_te[4][5];
+	__shared__ int32_t stage[ST_WORDS(4)];
+
+	// pass 1: OR of all samples (wasted bits) and whether they are all equal; the first tile stays
+	// staged (unshifted) for pass 2
+	const int32_t first = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start, s);
+	uint32_t orv = 0, ne = 0;
+	{
+		constexpr uint32_t HP = ST_HP(4);
+		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
+		for (uint32_t j = tid; j < n0; j += FA_THREADS) {
+			int32_t v = 0;
+			if (j >= HP && j - HP < bsf) {
+				v = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + (j - HP), s);
+				orv |= (uint32_t)v;
+				ne |= (uint32_t)(v != first);
+			}
+			stage[j + (j >> 4)] = v;
+		}
+		for (uint32_t i = FA_TILE + tid; i < bsf; i += FA_THREADS) {
+			const int32_t x = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + i, s);
+			orv |= (uint32_t)x;
+			ne |= (uint32_t)(x != first);
+		}
+	}
+	orv = wave_or(orv);
+	ne = wave_or(ne);
+	if ((tid & 63) == 0) {
+		sh_or[tid >> 6] = orv;
+		sh_ne[tid >> 6] = ne;
+	}
+	__syncthreads();
+	orv = sh_or[0] | sh_or[1] | sh_or[2] | sh_or[3];
+	ne = sh_ne[0] | sh_ne[1] | sh_ne[2] | sh_ne[3];
+	const uint32_t wasted = orv ? (uint32_t)__ffs((int)orv) - 1u : 0u;
+
+	uint64_t te[5] = {0, 0, 0, 0, 0};
+	if (bsf >= 4) {
+		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
+			if (tile > 0) {
+				__syncthreads();
+				stage_tile<4>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, 0, tile * FA_TILE);
+				__syncthreads();
+			}
+			const uint32_t base = tile * FA_TILE + tid * FA_CHUNK;
+			if (base >= bsf)
+				continue;
+			int32_t d[4 + FA_CHUNK];
+			load_chunk_lds<4>(d, stage);
+#pragma unroll
+			for (int k = 0; k < 4 + FA_CHUNK; k++)
+				d[k] >>= wasted;
+			// the wide (64-bit) sums are only needed when a partial sum could pass 2^32
+			uint32_t t32[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++) {
+				const uint32_t idx = base + i;
+				if (idx >= 4 && idx < bsf) {
+					const uint32_t a = (uint32_t)d[4 + i], b = (uint32_t)d[3 + i], c = (uint32_t)d[2 + i], e = (uint32_t)d[1 + i], g = (uint32_t)d[i];
+					const uint32_t e0 = abs32((int32_t)a), e1 = abs32((int32_t)(a - b)), e2 = abs32((int32_t)(a - 2 * b + c));
+					const uint32_t e3 = abs32((int32_t)(a - 3 * b + 3 * c - e)), e4 = abs32((int32_t)(a - 4 * b + 6 * c - 4 * e + g));
+					if (P.wide_fixed) {
+						te[0] += e0; te[1] += e1; te[2] += e2; te[3] += e3; te[4] += e4;
+					} else {
+						t32[0] += e0; t32[1] += e1; t32[2] += e2; t32[3] += e3; t32[4] += e4;
+					}
+				}
+			}
+			if (!P.wide_fixed)
+				for (int k = 0; k < 5; k++)
+					te[k] += t32[k];  // wraps like the reference's uint32 accumulators after the final mask
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 5; k++)
+		te[k] = wave_sum64(te[k]);
+	if ((tid & 63) == 0)
+		for (int k = 0; k < 5; k++)
+			sh_te[tid >> 6][k] = te[k];
+	__syncthreads();
+	if (tid == 0) {
+		FaSubStat st;
+		st.wasted = wasted;
+		st.bps = P.bps - wasted + ((P.do_ms && s == P.channels + 1) ? 1u : 0u);
+		st.first_sample = first >> wasted;
+		st.is_constant = 0;
+		st.fixed_guess = 0;
+		for (int k = 0; k < 5; k++)
+			st.rbps[k] = 0.0f;
+		if (bsf >= 4) {
+			uint64_t t[5];
+			for (int k = 0; k < 5; k++) {
+				t[k] = sh_te[0][k] + sh_te[1][k] + sh_te[2][k] + sh_te[3][k];
+				if (!P.wide_fixed)
+					t[k] &= 0xffffffffull;  // uint32 accumulators wrap (fixed.c:234)
+			}
+			auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
+			uint32_t order;
+			if (t[0] < mn(mn(mn(t[1], t[2]), t[3]), t[4])) order = 0;
+			else if (t[1] < mn(mn(t[2], t[3]), t[4])) order = 1;
+			else if (t[2] < mn(t[3], t[4])) order = 2;
+			else if (t[3] < t[4]) order = 3;
+			else order = 4;
+			st.fixed_guess = order;
+			const double n = (double)(bsf - 4);
+			for (int k = 0; k < 5; k++)
+				st.rbps[k] = (float)(t[k] > 0 ? log(M_LN2 * (double)t[k] / n) / M_LN2 : 0.0);
+			st.is_constant = (!P.disable_constant && st.rbps[1] == 0.0f && ne == 0) ? 1u : 0u;
+		}
+		stats[task] = st;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_autoc: FLAC__lpc_window_data (lpc.c:56) + FLAC__lpc_compute_autocorrelation (lpc.c:63).
+// The reference adds the products of one lag in sample order into a float accumulator; each
+// (task, lag) lane here walks the samples in that same order, so the sums are the same floats.
+// Samples are staged through LDS in tiles; positions past the frame are zero, and adding the
+// resulting +-0 products leaves an accumulator unchanged.
+// ---------------------------------------------------------------------------------------------
+#define AC_TILE 256
+#define AC_MAXTASKS 16
+// Row stride AC_TILE + lag: AC_TILE is a multiple of 32, so lane (task j, lag l) = thread j*lag + l
+// reads bank (thread + sample) mod 32 and a half-wave never collides.
+#define AC_LDS_FLOATS (AC_MAXTASKS * (AC_TILE + FA_MAX_ORDER + 1))
+
+__global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
+                                                       const float *windows, float *autoc, uint32_t tasks_per_block)
+{
+	__shared__ float x[AC_LDS_FLOATS];
+	const uint32_t lag = P.max_lpc_order + 1;
+	const uint32_t row_len = AC_TILE + lag;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
+	const uint32_t task0 = blockIdx.x * tasks_per_block;
+	const uint32_t my_j = tid / lag, my_l = tid % lag;
+	const bool active = my_j < tasks_per_block && task0 + my_j < ntasks;
+	float acc = 0.0f;
+
+	for (uint32_t c0 = 0; c0 < P.blocksize; c0 += AC_TILE) {
+		// stage tile [c0, c0 + AC_TILE + lag) of every task's windowed signal
+		for (uint32_t e = tid; e < tasks_per_block * row_len; e += FA_THREADS) {
+			const uint32_t j = e / row_len, k = e % row_len;
+			const uint32_t task = task0 + j;
+			float v = 0.0f;
+			if (task < ntasks) {
+				const uint32_t sub = task / P.napod, a = task % P.napod;
+				const uint32_t f = sub / P.nsignals, s = sub % P.nsignals;
+				const uint32_t bsf = frame_len(B, P.blocksize, f);
+				const uint32_t idx = c0 + k;
+				if (idx < bsf) {
+					const int32_t smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, (uint64_t)f * P.blocksize + idx, s) >> stats[sub].wasted;
+					v = __fmul_rn((float)smp, windows[(size_t)a * P.blocksize + idx]);
+				}
+			}
+			x[e] = v;
+		}
+		__syncthreads();
+		if (active) {
+			const float *row = x + my_j * row_len;
+#pragma unroll 8
+			for (uint32_t sidx = 0; sidx < AC_TILE; sidx++)
+				acc = __fadd_rn(acc, __fmul_rn(row[sidx], row[sidx + my_l]));
+		}
+		__syncthreads();
+	}
+	if (active)
+		autoc[(size_t)(task0 + my_j) * (FA_MAX_ORDER + 1) + my_l] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lpc: per (frame, signal) lane: FLAC__lpc_compute_lp_coefficients (lpc.c:112),
+// FLAC__lpc_compute_best_order (lpc.c:1353), expected bits (lpc.c:1325-1351), and
+// FLAC__lpc_quantize_coefficients (lpc.c:156) for every candidate process_subframe_ would try
+// (stream_encoder.c:3292-3382).  Per-lane arrays live in LDS, indexed [element][lane].
+// ---------------------------------------------------------------------------------------------
+#define LPC_LANES 64
+
+__device__ __forceinline__ double expected_bits_scaled(double lpc_error, double error_scale)
+{
+	if (lpc_error > 0.0) {
+		const double bps = (double)0.5 * log(error_scale * lpc_error) / M_LN2;
+		return bps >= 0.0 ? bps : 0.0;
+	}
+	if (lpc_error < 0.0)
+		return 1e32;
+	return 0.0;
+}
+
+// One Levinson-Durbin step i (0-based): updates lpc[0..i] and err.  lpc is the lane's LDS column.
+__device__ __forceinline__ void levinson_step(uint32_t i, const float *ac, double *lpc, uint32_t lane, double &err)
+{
+	double r = -(double)ac[(i + 1) * LPC_LANES + lane];
+	for (uint32_t j = 0; j < i; j++)
+		r -= lpc[j * LPC_LANES + lane] * (double)ac[(i - j) * LPC_LANES + lane];
+	r /= err;
+	lpc[i * LPC_LANES + lane] = r;
+	uint32_t j;
+	for (j = 0; j < (i >> 1); j++) {
+		const double tmp = lpc[j * LPC_LANES + lane];
+		lpc[j * LPC_LANES + lane] = tmp + r * lpc[(i - 1 - j) * LPC_LANES + lane];
+		lpc[(i - 1 - j) * LPC_LANES + lane] += r * tmp;
+	}
+	if (i & 1)
+		lpc[j * LPC_LANES + lane] += lpc[j * LPC_LANES + lane] * r;
+	err *= (1.0 - r * r);
+}
+
+__global__ __launch_bounds__(LPC_LANES) void k_lpc(FaEncParams P, FaBatch B, const FaSubStat *stats, const float *autoc,
+                                                   FaLpcCand *cands, int32_t *coefs)
+{
+	__shared__ double lpc[FA_MAX_ORDER * LPC_LANES];
+	__shared__ double errs[FA_MAX_ORDER * LPC_LANES];
+	__shared__ float ac[(FA_MAX_ORDER + 1) * LPC_LANES];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t sub = blockIdx.x * LPC_LANES + lane;
+	const uint32_t nsub = B.nframes * P.nsignals;
+	if (sub >= nsub)
+		return;
+	const uint32_t f = sub / P.nsignals;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);
+	const FaSubStat st = stats[sub];
+	FaLpcCand *my_cands = cands + (size_t)sub * P.ncand;
+	int32_t *my_coefs = coefs + (size_t)sub * P.ncand * P.max_lpc_order;
+	FaLpcCand none;
+	none.valid = 0; none.order = 0; none.precision = 0; none.shift = 0; none.rice = 0; none.wide = 0; none.pad[0] = none.pad[1] = 0;
+	for (uint32_t c = 0; c < P.ncand; c++)
+		my_cands[c] = none;
+	if (bsf < 4 || st.is_constant || P.max_lpc_order == 0)
+		return;
+	uint32_t max_lpc = P.max_lpc_order >= bsf ? bsf - 1 : P.max_lpc_order;
+	if (max_lpc == 0)
+		return;
+	const uint32_t sbps = st.bps;
+
+	for (uint32_t a = 0; a < P.napod; a++) {
+		const float *src = autoc + (size_t)(sub * P.napod + a) * (FA_MAX_ORDER + 1);
+		for (uint32_t l = 0; l <= max_lpc; l++)
+			ac[l * LPC_LANES + lane] = src[l];
+		if (ac[lane] == 0.0f)
+			continue;  // stream_encoder.c:3303
+		// pass 1: prediction errors of every order (lpc.c:122-153)
+		double err = (double)ac[lane];
+		for (uint32_t i = 0; i < max_lpc; i++) {
+			levinson_step(i, ac, lpc, lane, err);
+			errs[i * LPC_LANES + lane] = err;
+			if (err == 0.0) {
+				max_lpc = i + 1;
+				break;
+			}
+		}
+		uint32_t min_lpc;
+		if (P.exhaustive)
+			min_lpc = 1;
+		else {
+			// lpc.c:1353
+			const uint32_t overhead = sbps + (P.prec_search ? 5u : P.qlp_precision);
+			const double scale = 0.5 * M_LN2 * M_LN2 / (double)bsf;
+			uint32_t best = 0;
+			double best_bits = (double)(unsigned)(-1);
+			for (uint32_t idx = 0, order = 1; idx < max_lpc; idx++, order++) {
+				const double bits = expected_bits_scaled(errs[idx * LPC_LANES + lane], scale) * (double)(bsf - order) + (double)(order * overhead);
+				if (bits < best_bits) {
+					best = idx;
+					best_bits = bits;
+				}
+			}
+			min_lpc = max_lpc = best + 1;
+		}
+		if (max_lpc >= bsf)
+			max_lpc = bsf - 1;
+		// pass 2: the same recursion again; quantise at the orders that are tried
+		err = (double)ac[lane];
+		for (uint32_t i = 0; i < max_lpc; i++) {
+			levinson_step(i, ac, lpc, lane, err);
+			const uint32_t order = i + 1;
+			if (order < min_lpc)
+				continue;
+			const double scale = 0.5 * M_LN2 * M_LN2 / (double)(bsf - order);
+			const double lbps = expected_bits_scaled(errs[i * LPC_LANES + lane], scale);
+			if (lbps >= (double)sbps)
+				continue;  // stream_encoder.c:3326
+			uint32_t rice = (lbps > 0.0) ? (uint32_t)(lbps + 0.5) : 0u;
+			rice++;
+			if (rice >= P.rice_limit)
+				rice = P.rice_limit - 1;
+			uint32_t pmin, pmax;
+			if (P.prec_search) {
+				pmin = 5;
+				if (sbps <= 17) {
+					pmax = umin32(32 - sbps - order, 15u);
+					pmax = umax32(pmax, pmin);
+				} else
+					pmax = 15;
+			} else
+				pmin = pmax = P.qlp_precision;
+			// cmax = max |coefficient| of this order (lpc.c:172-177); the coefficients are
+			// the negated recursion state rounded to float (lpc.c:145)
+			double cmax = 0.0;
+			for (uint32_t j = 0; j <= i; j++) {
+				const double dd = fabs((double)(float)(-lpc[j * LPC_LANES + lane]));
+				if (dd > cmax)
+					cmax = dd;
+			}
+			for (uint32_t prec = pmin; prec <= pmax; prec++) {
+				const uint32_t slot = (a * P.max_lpc_order + i) * P.nprec + (P.prec_search ? prec - 5 : 0);
+				uint32_t precision = prec;
+				if (sbps <= 16)
+					precision = umin32(precision, 32 - sbps - ilog2u(order));  // stream_encoder.c:3582-3586
+				// lpc.c:156
+				const uint32_t pm1 = precision - 1;
+				int32_t qmax = 1 << pm1;
+				const int32_t qmin = -qmax;
+				qmax--;
+				if (cmax <= 0.0)
+					continue;
+				int log2cmax;
+				(void)frexp(cmax, &log2cmax);
+				log2cmax--;
+				int shift = (int)pm1 - log2cmax - 1;
+				if (shift > 15)
+					shift = 15;
+				else if (shift < -16)
+					continue;
+				double qerr = 0.0;
+				int32_t *q = my_coefs + (size_t)slot * P.max_lpc_order;
+				for (uint32_t j = 0; j <= i; j++) {
+					const float c = (float)(-lpc[j * LPC_LANES + lane]);
+					if (shift >= 0)
+						qerr += (double)(c * (float)(1 << shift));
+					else
+						qerr += (double)(c / (float)(1 << (-shift)));
+					int32_t v = qerr >= 0.0 ? (int32_t)(qerr + 0.5) : (int32_t)(qerr - 0.5);
+					if (v > qmax) v = qmax;
+					else if (v < qmin) v = qmin;
+					qerr -= v;
+					q[j] = v;
+				}
+				FaLpcCand cd;
+				cd.valid = 1;
+				cd.order = (uint8_t)order;
+				cd.precision = (uint8_t)precision;
+				cd.shift = (int8_t)(shift < 0 ? 0 : shift);
+				cd.rice = (uint8_t)rice;
+				cd.wide = (sbps + precision + ilog2u(order) <= 32) ? 0 : 1;  // stream_encoder.c:3592
+				cd.pad[0] = cd.pad[1] = 0;
+				my_cands[slot] = cd;
+			}
+		}
+	}
+}
+// ---------------------------------------------------------------------------------------------
+// k_decide: channel assignment (stream_encoder.c:3047-3082) incl. the loose mid/side rule
+// (:2952-2962): within a period every frame follows its leader frame's decision.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t assignment_argmin(const FaPlan *p /* L,R,M,S */)
+{
+	const uint32_t b0 = p[0].bits + p[1].bits, b1 = p[0].bits + p[3].bits, b2 = p[1].bits + p[3].bits, b3 = p[2].bits + p[3].bits;
+	uint32_t ca = 0, mn = b0;
+	if (b1 < mn) { mn = b1; ca = 1; }
+	if (b2 < mn) { mn = b2; ca = 2; }
+	if (b3 < mn) { mn = b3; ca = 3; }
+	return ca;
+}
+
+__global__ void k_decide(FaEncParams P, FaBatch B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out)
+{
+	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= B.nframes)
+		return;
+	uint32_t ca = 0;
+	if (P.do_ms) {
+		if (P.loose_ms) {
+			const uint32_t gnum = B.first_frame + f;
+			const uint32_t phase = gnum % P.loose_frames;
+			if (phase == 0)
+				ca = assignment_argmin(plans + (size_t)f * P.nsignals);
+			else {
+				uint32_t lead;
+				if (phase > f)
+					lead = B.loose_carry;  // the leader was in an earlier batch
+				else
+					lead = assignment_argmin(plans + (size_t)(f - phase) * P.nsignals);
+				ca = lead == 0 ? 0 : 3;
+			}
+		} else
+			ca = assignment_argmin(plans + (size_t)f * P.nsignals);
+	}
+	assign[f] = ca;
+	if (f == B.nframes - 1)
+		*loose_out = ca;
+}
+// ---------------------------------------------------------------------------------------------
+// k_scan: exclusive prefix sum of the frame sizes (single block)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets)
+{
+	__shared__ uint64_t wsum[16];
+	__shared__ uint64_t carry;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0)
+		carry = 0;
+	__syncthreads();
+	for (uint32_t base = 0; base < n; base += 1024) {
+		const uint32_t i = base + tid;
+		const uint64_t v = i < n ? frame_bytes[i] : 0;
+		uint64_t inc = v;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const uint64_t t = __shfl_up(inc, o, 64);
+			if (lane >= (uint32_t)o)
+				inc += t;
+		}
+		if (lane == 63)
+			wsum[wv] = inc;
+		__syncthreads();
+		uint64_t off = carry;
+		for (uint32_t w = 0; w < wv; w++)
+			off += wsum[w];
+		if (i < n)
+			offsets[i] = off + inc - v;
+		__syncthreads();
+		if (tid == 1023)
+			carry = off + inc;
+		__syncthreads();
+	}
+	if (tid == 0)
+		offsets[n] = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compact: frame slots -> back-to-back frames
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FA_THREADS) void k_compact(const uint32_t *slots, uint32_t slot_bytes, const uint32_t *frame_bytes,
+                                                        const uint64_t *offsets, uint8_t *out, uint64_t out_capacity, uint32_t *errflag)
+{
+	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t n = frame_bytes[f];
+	const uint64_t off = offsets[f];
+	if (off + n > out_capacity) {
+		if (tid == 0)
+			atomicOr(errflag, 2u);
+		return;
+	}
+	const uint8_t *src = (const uint8_t *)slots + (size_t)f * slot_bytes;
+	uint8_t *dst = out + off;
+	// leading bytes up to 4-byte alignment of dst, then aligned words, then the tail
+	const uint32_t head = umin32((uint32_t)((4 - (off & 3)) & 3), n);
+	if (tid < head)
+		dst[tid] = src[tid];
+	const uint32_t nwords = (n - head) / 4;
+	uint32_t *dw = (uint32_t *)(dst + head);
+	for (uint32_t w = tid; w < nwords; w += FA_THREADS) {
+		const uint8_t *p = src + head + 4 * (size_t)w;
+		// src is 4-byte aligned only when head == 0: assemble from two aligned words
+		const uint32_t sh = (uint32_t)((uintptr_t)p & 3);
+		const uint32_t *pa = (const uint32_t *)(p - sh);
+		uint32_t v = pa[0];
+		if (sh)
+			v = (v >> (8 * sh)) | (pa[1] << (32 - 8 * sh));
+		dw[w] = v;
+	}
+	const uint32_t done = head + nwords * 4;
+	if (tid < n - done)
+		dst[done + tid] = src[done + tid];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_widen: host int32 samples are already int32; helper for the decoder tests is elsewhere.
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_analyze, dim3(B.nframes * P.nsignals), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
+}
+
+void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,
+                     hipStream_t st)
+{
+	const uint32_t lag = P.max_lpc_order + 1;
+	uint32_t tpb = FA_THREADS / lag;
+	if (tpb > AC_MAXTASKS)
+		tpb = AC_MAXTASKS;
+	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
+	hipLaunchKernelGGL(k_autoc, dim3((ntasks + tpb - 1) / tpb), dim3(FA_THREADS), 0, st, P, B, pcm, stats, windows, autoc, tpb);
+}
+
+void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stats, const float *autoc, FaLpcCand *cands, int32_t *coefs,
+                   hipStream_t st)
+{
+	const uint32_t nsub = B.nframes * P.nsignals;
+	hipLaunchKernelGGL(k_lpc, dim3((nsub + LPC_LANES - 1) / LPC_LANES), dim3(LPC_LANES), 0, st, P, B, stats, autoc, cands, coefs);
+}
+
+void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_decide, dim3((B.nframes + 255) / 256), dim3(256), 0, st, P, B, plans, assign, loose_out);
+}
+
+void fa_launch_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, frame_bytes, n, offsets);
+}
+
+void fa_launch_compact(const FaEncParams &P, const FaBatch &B, const uint32_t *slots, const uint32_t *frame_bytes, const uint64_t *offsets,
+                       uint8_t *out, uint64_t out_capacity, uint32_t *errflag, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_compact, dim3(B.nframes), dim3(FA_THREADS), 0, st, slots, P.slot_bytes, frame_bytes, offsets, out, out_capacity, errflag);
+}

@@ -1,0 +1,269 @@
+// Device helpers shared by the encoder kernels: PCM access, staging of a frame's signal through
+// LDS, residual arithmetic, Rice parameter estimates.
+#ifndef FLAC_AMD_ENC_COMMON_H
+#define FLAC_AMD_ENC_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include "flac_amd_internal.h"
+
+#ifndef M_LN2
+#define M_LN2 0.69314718055994530942
+#endif
+
+__device__ __forceinline__ uint32_t ilog2u(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ __forceinline__ uint32_t ilog2u64(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }
+__device__ __forceinline__ uint32_t abs32(int32_t x) { return x < 0 ? 0u - (uint32_t)x : (uint32_t)x; }
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint32_t frame_len(const FaBatch &B, uint32_t bs, uint32_t f)
+{
+	const uint64_t start = (uint64_t)f * bs;
+	const uint64_t rem = B.wide_samples - start;
+	return rem < bs ? (uint32_t)rem : bs;
+}
+
+__device__ __forceinline__ int32_t read_pcm(const void *pcm, uint32_t sample_bytes, uint64_t idx)
+{
+	if (sample_bytes == 2)
+		return ((const int16_t *)pcm)[idx];
+	if (sample_bytes == 4)
+		return ((const int32_t *)pcm)[idx];
+	const uint8_t *b = (const uint8_t *)pcm + idx * 3;
+	return (int32_t)((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)(int32_t)(int8_t)b[2] << 16));
+}
+
+// Signal s of a wide sample: an input channel, or mid = (L+R)>>1 / side = L-R
+// (stream_encoder.c:1991-1992, arithmetic shift, not a division).  `pairs`: the buffer is 16-bit
+// stereo on a 4-byte boundary, so one 32-bit load brings both channels.
+__device__ __forceinline__ int32_t fetch_signal(const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs, uint64_t wide, uint32_t s)
+{
+	if (pairs) {
+		const uint32_t w = ((const uint32_t *)pcm)[wide];
+		const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
+		return s == 0 ? l : s == 1 ? r : s == 2 ? ((l + r) >> 1) : (l - r);
+	}
+	if (s < channels)
+		return read_pcm(pcm, sample_bytes, wide * channels + s);
+	const int32_t l = read_pcm(pcm, sample_bytes, wide * channels);
+	const int32_t r = read_pcm(pcm, sample_bytes, wide * channels + 1);
+	return s == channels ? ((l + r) >> 1) : (l - r);
+}
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v |= __shfl_xor(v, o, 64);
+	return v;
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v += __shfl_xor(v, o, 64);
+	return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staging.  A workgroup covers FA_TILE samples per pass, thread t owning samples
+// [16 t, 16 t + 16) of the tile plus HIST samples of history in front of them.  The tile (with
+// ST_HP(HIST) samples of history, a multiple of 16) is read from global memory with lanes along
+// consecutive samples and stored in LDS in rows of 16 samples padded to 17 words: thread t then
+// reads row t + const at a fixed column, i.e. word 17 t + const, which spreads a wave over all banks.
+// ---------------------------------------------------------------------------------------------
+#define ST_HP(H) (((H) + 15) & ~15)
+#define ST_ROWS(H) ((ST_HP(H) + FA_TILE) / 16)
+#define ST_WORDS(H) (ST_ROWS(H) * 17)
+
+// Stage samples [tile_base - ST_HP, tile_base + tile_len16) of signal s, shifted right by `wasted`;
+// positions outside the frame read as 0.  tile_len16 = samples of the tile in the frame, rounded up
+// to whole rows.
+template <int HIST>
+__device__ __forceinline__ void stage_tile(int32_t *lds, const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs,
+                                           uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t wasted, uint32_t tile_base)
+{
+	constexpr uint32_t HP = ST_HP(HIST);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	uint32_t tile_len = bsf - tile_base;
+	if (tile_len > FA_TILE)
+		tile_len = FA_TILE;
+	const uint32_t n = HP + ((tile_len + 15) & ~15u);
+	// all loads are issued before the first store, at clamped (always valid) positions
+	int32_t v[NIT];
+#pragma unroll
+	for (uint32_t i = 0; i < NIT; i++) {
+		const uint32_t j = threadIdx.x + i * FA_THREADS;
+		int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
+		const bool inside = idx >= 0 && (uint32_t)idx < bsf;
+		idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+		const int32_t x = fetch_signal(pcm, channels, sample_bytes, pairs, frame_start + (uint32_t)idx, s);
+		v[i] = inside ? (x >> wasted) : 0;
+	}
+#pragma unroll
+	for (uint32_t i = 0; i < NIT; i++) {
+		const uint32_t j = threadIdx.x + i * FA_THREADS;
+		if (j < n)
+			lds[j + (j >> 4)] = v[i];
+	}
+}
+
+// d[k] = sample (16 t - HIST + k) of the staged tile, k = 0 .. HIST + 15
+template <int HIST>
+__device__ __forceinline__ void load_chunk_lds(int32_t (&d)[HIST + FA_CHUNK], const int32_t *lds)
+{
+	constexpr int HP = ST_HP(HIST);
+	const int32_t *row = lds + (threadIdx.x + HP / 16) * 17;
+#pragma unroll
+	for (int k = 0; k < HIST + FA_CHUNK; k++) {
+		const int rel = k - HIST;                    // -HIST .. 15
+		const int r = rel >= 0 ? 0 : -((-rel + 15) / 16);  // floor(rel / 16)
+		const int c = rel - 16 * r;
+		d[k] = row[r * 17 + c];
+	}
+}
+
+// format.c:548: largest partition order whose first partition still holds more than the warm-up
+__device__ __forceinline__ uint32_t limit_part_order(uint32_t limit, uint32_t bs, uint32_t pred_order)
+{
+	uint32_t o = limit;
+	while (o > 0 && (bs >> o) <= pred_order)
+		o--;
+	return o;
+}
+
+// stream_encoder.c:4047-4054: smallest k with n << k >= sum, clamped below the escape code
+__device__ __forceinline__ uint32_t rice_k_from_sum(uint64_t sum, uint32_t n, uint32_t limit)
+{
+	uint32_t k = 0;
+	if (sum > n) {
+		const uint32_t a = ilog2u64(sum), b = ilog2u(n);
+		k = a - b;
+		if (((uint64_t)n << k) < sum)
+			k++;
+	}
+	if (k >= limit)
+		k = limit - 1;
+	return k;
+}
+
+// stream_encoder.c:3918 count_rice_bits_in_partition_ (sum-based estimate; unsigned wraparound kept)
+__device__ __forceinline__ uint32_t rice_bits_estimate(uint32_t k, uint32_t n, uint64_t sum)
+{
+	return 4u + (1u + k) * n + (k ? (uint32_t)(sum >> (k - 1)) : (uint32_t)(sum << 1)) - (n >> 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual arithmetic: d[HIST + i] is sample i of the thread's chunk; res[i] for its 16 samples
+// ---------------------------------------------------------------------------------------------
+// FLAC__fixed_compute_residual (fixed.c:352)
+template <int HIST>
+__device__ __forceinline__ void fixed_residual16(const int32_t (&d)[HIST + FA_CHUNK], uint32_t order, int32_t (&res)[FA_CHUNK])
+{
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++) {
+		const uint32_t a = (uint32_t)d[HIST + i], b = (uint32_t)d[HIST + i - 1], c = (uint32_t)d[HIST + i - 2], e = (uint32_t)d[HIST + i - 3],
+		               g = (uint32_t)d[HIST + i - 4];
+		uint32_t r;
+		switch (order) {
+		case 0: r = a; break;
+		case 1: r = a - b; break;
+		case 2: r = a - 2 * b + c; break;
+		case 3: r = a - 3 * b + 3 * c - e; break;
+		default: r = a - 4 * b + 6 * c - 4 * e + g; break;
+		}
+		res[i] = (int32_t)r;
+	}
+}
+
+// FLAC__lpc_compute_residual_from_qlp_coefficients (lpc.c:265, int32 sum that wraps) and _wide
+// (lpc.c:531, int64 sum).  MODE 0: 24x24-bit multiplies (operands known to fit), wrapping int32
+// sum.  MODE 1: int64 sum truncated to int32 before the shift (== the wrapping int32 sum).
+// MODE 2: int64 sum, shifted, then truncated.  `order` and q[] are the same for every lane: taps
+// are added one at a time under a scalar branch, with the coefficient in a scalar register, so one
+// copy of the code serves every order up to MAXORDER.
+template <int HIST, int MAXORDER, int MODE>
+__device__ __forceinline__ void lpc_residual16_taps(const int32_t (&d)[HIST + FA_CHUNK], const int32_t *__restrict__ q, uint32_t order, int shift,
+                                                    int32_t (&res)[FA_CHUNK])
+{
+	if (MODE == 0) {
+		int32_t sum[FA_CHUNK];
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			sum[i] = 0;
+#pragma unroll
+		for (int j = 0; j < MAXORDER; j++) {
+			if ((uint32_t)j < order) {
+				const int32_t qj = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)q[j]);
+#pragma unroll
+				for (int i = 0; i < FA_CHUNK; i++)
+					sum[i] += __mul24(qj, d[HIST + i - 1 - j]);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			res[i] = (int32_t)((uint32_t)d[HIST + i] - (uint32_t)(sum[i] >> shift));
+	} else {
+		int64_t sum[FA_CHUNK];
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			sum[i] = 0;
+#pragma unroll
+		for (int j = 0; j < MAXORDER; j++) {
+			if ((uint32_t)j < order) {
+				const int64_t qj = (int64_t)(int32_t)__builtin_amdgcn_readfirstlane((uint32_t)q[j]);
+#pragma unroll
+				for (int i = 0; i < FA_CHUNK; i++)
+					sum[i] += qj * (int64_t)d[HIST + i - 1 - j];
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++) {
+			const int32_t pred = (MODE == 1) ? ((int32_t)sum[i] >> shift) : (int32_t)(sum[i] >> shift);
+			res[i] = (int32_t)((uint32_t)d[HIST + i] - (uint32_t)pred);
+		}
+	}
+}
+
+// NARROW: the caller knows every candidate of the stream is MODE 0 (see fa_narrow_only)
+template <int HIST, bool NARROW>
+__device__ __forceinline__ void lpc_residual16_any(const int32_t (&d)[HIST + FA_CHUNK], const int32_t *q, uint32_t order, int shift, int mode,
+                                                   int32_t (&res)[FA_CHUNK])
+{
+	constexpr int MAXORDER = HIST < FA_MAX_ORDER ? HIST : FA_MAX_ORDER;
+	if (NARROW || mode == 0)
+		lpc_residual16_taps<HIST, MAXORDER, 0>(d, q, order, shift, res);
+	else if (mode == 1)
+		lpc_residual16_taps<HIST, MAXORDER, 1>(d, q, order, shift, res);
+	else
+		lpc_residual16_taps<HIST, MAXORDER, 2>(d, q, order, shift, res);
+}
+
+// which arithmetic the residual of an LPC candidate needs
+__device__ __forceinline__ int lpc_mode(uint32_t wide, uint32_t sbps) { return wide ? 2 : (sbps <= 24 ? 0 : 1); }
+
+// True when no LPC candidate of a stream with these settings can need 64-bit arithmetic or full
+// 32-bit multiplies: subframe samples fit 24 bits and the reference's own rule
+// bps + precision + ilog2(order) <= 32 (stream_encoder.c:3592) holds for the largest values possible.
+static inline bool fa_narrow_only(const FaEncParams &P)
+{
+	if (P.max_lpc_order == 0)
+		return true;
+	const uint32_t max_sbps = P.bps + (P.do_ms ? 1u : 0u);
+	const uint32_t max_prec = P.prec_search ? 15u : P.qlp_precision;
+	uint32_t lg = 0;
+	while ((2u << lg) <= P.max_lpc_order)
+		lg++;
+	return max_sbps <= 24 && max_sbps + max_prec + lg <= 32;
+}
+
+static inline int fa_hist_class(const FaEncParams &P)
+{
+	if (P.max_lpc_order == 0)
+		return 4;
+	return P.max_lpc_order <= 12 ? 12 : 32;
+}
+
+#endif

@@ -1,4 +1,4 @@
-// Launchers of the encoder kernels (enc_kernels.hip).
+// Launchers of the encoder kernels (enc_analyze.hip, enc_search.hip, enc_pack.hip).
 #ifndef FLAC_AMD_ENC_KERNELS_H
 #define FLAC_AMD_ENC_KERNELS_H
 
@@ -6,7 +6,6 @@
 
 #include "flac_amd_internal.h"
 
-size_t fa_search_lds_bytes(void);
 void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st);
 void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,

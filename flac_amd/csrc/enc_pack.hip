@@ -1,0 +1,490 @@
+// FLAC frame encoder kernels for gfx950 (MI355X), part 3: bit packing of the chosen subframes.
+#include <hip/hip_runtime.h>
+
+#include "enc_common.h"
+#include "enc_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_pack
+// ---------------------------------------------------------------------------------------------
+#define PK_CAPW 8192  // window of the frame's bitstream held in LDS, in 32-bit words
+
+__constant__ uint16_t c_crc16_table[256];
+__constant__ uint16_t c_crc16_pow[32];  // x^(8 * 2^j) mod the CRC-16 polynomial
+__constant__ uint8_t c_crc8_table[256];
+
+void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
+{
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_table), t16, 512);
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_pow), pow16, 64);
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc8_table), t8, 256);
+}
+
+// product of two polynomials modulo x^16 + x^15 + x^2 + 1
+__device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
+{
+	uint32_t r = 0;
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		if (b & 1)
+			r ^= a;
+		b >>= 1;
+		a <<= 1;
+		if (a & 0x10000)
+			a ^= 0x18005;
+	}
+	return r;
+}
+
+// x^(8 n) modulo the polynomial
+__device__ __forceinline__ uint32_t gf16_xpow8(uint32_t n)
+{
+	uint32_t r = 1;
+	for (int j = 0; n; j++, n >>= 1)
+		if (n & 1)
+			r = gf16_mul(r, c_crc16_pow[j]);
+	return r;
+}
+
+struct PkShared {
+	uint32_t W[PK_CAPW];
+	uint32_t scan[4];
+	uint32_t crcs[FA_THREADS];
+	uint16_t crc_table[256];
+	uint32_t base_word;
+	uint32_t frame_crc;
+	uint32_t error;
+	uint8_t  params[FA_MAX_PARTS];
+	int32_t  q[FA_MAX_ORDER];
+};
+
+template <int HIST>
+struct PkStage {
+	int32_t v[ST_WORDS(HIST)];
+};
+
+// OR the low nbits of value, MSB first, at bit position bitpos of the frame; only words inside
+// the LDS window are touched (zero bits never need writing: the window is pre-cleared).
+__device__ __forceinline__ void emit_bits(PkShared &S, uint32_t bitpos, uint32_t nbits, uint32_t value)
+{
+	if (nbits == 0)
+		return;
+	if (nbits < 32)
+		value &= (1u << nbits) - 1u;
+	const uint32_t w0 = bitpos >> 5, sh = bitpos & 31;
+	const uint64_t v = ((uint64_t)value << (64 - nbits)) >> sh;
+	const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+	const uint32_t r0 = w0 - S.base_word;  // wraps to a huge value for words already flushed
+	if (hi && r0 < PK_CAPW)
+		atomicOr(&S.W[r0], hi);
+	if (lo && r0 + 1 < PK_CAPW)
+		atomicOr(&S.W[r0 + 1], lo);
+}
+
+// Block-wide exclusive prefix sum of one uint32 per thread; returns the prefix, *total gets the sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(PkShared &S, uint32_t v, uint32_t *total)
+{
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	uint32_t inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(inc, o, 64);
+		if (lane >= (uint32_t)o)
+			inc += t;
+	}
+	__syncthreads();
+	if (lane == 63)
+		S.scan[wv] = inc;
+	__syncthreads();
+	uint32_t off = 0;
+	for (uint32_t w = 0; w < wv; w++)
+		off += S.scan[w];
+	*total = S.scan[0] + S.scan[1] + S.scan[2] + S.scan[3];
+	return off + inc - v;
+}
+
+// CRC-16 of nbytes bytes that start at window word 0 (FLAC__crc16, crc.c:134): each thread takes an
+// equal run of bytes, the runs are right-aligned (leading virtual zeros do not change a CRC that
+// starts at 0), and a tree folds them with multiplications by powers of x.
+__device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
+{
+	const uint32_t tid = threadIdx.x;
+	const uint32_t R = (nbytes + FA_THREADS - 1) / FA_THREADS;
+	uint32_t crc = 0;
+	if (R) {
+		const int64_t start = (int64_t)nbytes - (int64_t)(FA_THREADS - tid) * R;
+		for (uint32_t i = 0; i < R; i++) {
+			const int64_t b = start + i;
+			if (b >= 0) {
+				const uint32_t byte = (S.W[b >> 2] >> (24 - 8 * (b & 3))) & 0xff;
+				crc = ((crc << 8) & 0xffff) ^ S.crc_table[(crc >> 8) ^ byte];
+			}
+		}
+	}
+	S.crcs[tid] = crc;
+	__syncthreads();
+	uint32_t m = gf16_xpow8(R);
+	for (uint32_t L = 0; L < 8; L++) {
+		const uint32_t mask = (2u << L) - 1;
+		if ((tid & mask) == mask)
+			S.crcs[tid] = gf16_mul(S.crcs[tid - (1u << L)], m) ^ S.crcs[tid];
+		m = gf16_mul(m, m);
+		__syncthreads();
+	}
+	const uint32_t out = S.crcs[FA_THREADS - 1];
+	__syncthreads();
+	return out;
+}
+
+// Write window words [0, nwords) to the frame slot (big-endian bit order -> byte order), fold
+// their CRC into the frame CRC, slide the window.  keep_partial: word nwords holds the
+// unfinished tail and becomes word 0.
+__device__ __forceinline__ void flush_window(PkShared &S, uint32_t *slot, uint32_t slot_words, uint32_t nwords, bool keep_partial, bool with_crc)
+{
+	const uint32_t tid = threadIdx.x;
+	if (with_crc && nwords) {
+		const uint32_t c = window_crc16(S, nwords * 4);
+		if (tid == 0)
+			S.frame_crc = gf16_mul(S.frame_crc, gf16_xpow8(nwords * 4)) ^ c;
+	}
+	const uint32_t bw = S.base_word;
+	for (uint32_t w = tid; w < nwords; w += FA_THREADS) {
+		if (bw + w < slot_words)
+			slot[bw + w] = __builtin_bswap32(S.W[w]);
+		else
+			S.error = 1;
+	}
+	__syncthreads();
+	const uint32_t carry = keep_partial ? S.W[nwords] : 0u;
+	__syncthreads();
+	for (uint32_t w = tid; w < nwords + 2 && w < PK_CAPW; w += FA_THREADS)
+		S.W[w] = 0;
+	__syncthreads();
+	if (tid == 0) {
+		S.W[0] = carry;
+		S.base_word = bw + nwords;
+	}
+	__syncthreads();
+}
+
+// Emit everything the threads hold for bit range [*, end_bit) of the current tile, as many
+// window passes as it takes.  `emit` is called once per pass and must be idempotent.
+template <typename F>
+__device__ __forceinline__ void drain(PkShared &S, uint32_t *slot, uint32_t slot_words, uint32_t end_bit, F emit)
+{
+	for (;;) {
+		emit();
+		__syncthreads();
+		const uint32_t end_word = end_bit >> 5;  // first word that is not complete yet
+		const uint32_t bw = S.base_word;
+		if (end_word <= bw + PK_CAPW - 1) {
+			// everything fits: flush the complete words, keep the partial one
+			flush_window(S, slot, slot_words, end_word - bw, true, true);
+			return;
+		}
+		flush_window(S, slot, slot_words, PK_CAPW, false, true);
+	}
+}
+
+template <int HIST, bool NARROW>
+__global__ __launch_bounds__(FA_THREADS) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
+                                                     const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag)
+{
+	__shared__ PkShared S;
+	__shared__ PkStage<HIST> T;
+	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);
+	const uint64_t frame_start = (uint64_t)f * P.blocksize;
+	const uint32_t slot_words = P.slot_bytes / 4;
+	uint32_t *slot = slots + (size_t)f * slot_words;
+	const uint32_t ca = assign[f];
+
+	for (uint32_t w = tid; w < PK_CAPW; w += FA_THREADS)
+		S.W[w] = 0;
+	S.crc_table[tid] = c_crc16_table[tid];
+	if (tid == 0) {
+		S.base_word = 0;
+		S.frame_crc = 0;
+		S.error = 0;
+	}
+	__syncthreads();
+
+	// ---- frame header: FLAC__frame_add_header (stream_encoder_framing.c:219) ----
+	uint32_t bitpos;
+	{
+		uint8_t h[16];
+		uint32_t n = 0;
+		h[n++] = 0xff;
+		h[n++] = 0xf8;
+		uint32_t u, bs_hint = 0, sr_hint = 0;
+		switch (bsf) {
+		case 192: u = 1; break;
+		case 576: u = 2; break;
+		case 1152: u = 3; break;
+		case 2304: u = 4; break;
+		case 4608: u = 5; break;
+		case 256: u = 8; break;
+		case 512: u = 9; break;
+		case 1024: u = 10; break;
+		case 2048: u = 11; break;
+		case 4096: u = 12; break;
+		case 8192: u = 13; break;
+		case 16384: u = 14; break;
+		case 32768: u = 15; break;
+		default: bs_hint = u = bsf <= 0x100 ? 6 : 7; break;
+		}
+		uint32_t v;
+		switch (P.sample_rate) {
+		case 88200: v = 1; break;
+		case 176400: v = 2; break;
+		case 192000: v = 3; break;
+		case 8000: v = 4; break;
+		case 16000: v = 5; break;
+		case 22050: v = 6; break;
+		case 24000: v = 7; break;
+		case 32000: v = 8; break;
+		case 44100: v = 9; break;
+		case 48000: v = 10; break;
+		case 96000: v = 11; break;
+		default:
+			if (P.sample_rate <= 255000 && P.sample_rate % 1000 == 0) sr_hint = v = 12;
+			else if (P.sample_rate % 10 == 0) sr_hint = v = 14;
+			else if (P.sample_rate <= 0xffff) sr_hint = v = 13;
+			else v = 0;
+			break;
+		}
+		h[n++] = (uint8_t)((u << 4) | v);
+		const uint32_t chcode = ca == 0 ? P.channels - 1 : 7 + ca;
+		uint32_t bcode;
+		switch (P.bps) {
+		case 8: bcode = 1; break;
+		case 12: bcode = 2; break;
+		case 16: bcode = 4; break;
+		case 20: bcode = 5; break;
+		case 24: bcode = 6; break;
+		default: bcode = 0; break;
+		}
+		h[n++] = (uint8_t)((chcode << 4) | (bcode << 1));
+		// FLAC__bitwriter_write_utf8_uint32 (bitwriter.c:784)
+		const uint32_t val = B.first_frame + f;
+		if (val < 0x80)
+			h[n++] = (uint8_t)val;
+		else {
+			const int cont = val < 0x800 ? 1 : val < 0x10000 ? 2 : val < 0x200000 ? 3 : val < 0x4000000 ? 4 : 5;
+			const uint32_t lead = (0xff00u >> (cont + 1)) & 0xff;  // 0xC0, 0xE0, 0xF0, 0xF8, 0xFC
+			h[n++] = (uint8_t)(lead | (val >> (6 * cont)));
+			for (int i = cont - 1; i >= 0; i--)
+				h[n++] = (uint8_t)(0x80 | ((val >> (6 * i)) & 0x3f));
+		}
+		if (bs_hint == 6)
+			h[n++] = (uint8_t)(bsf - 1);
+		else if (bs_hint == 7) {
+			h[n++] = (uint8_t)((bsf - 1) >> 8);
+			h[n++] = (uint8_t)(bsf - 1);
+		}
+		if (sr_hint == 12)
+			h[n++] = (uint8_t)(P.sample_rate / 1000);
+		else if (sr_hint == 13) {
+			h[n++] = (uint8_t)(P.sample_rate >> 8);
+			h[n++] = (uint8_t)P.sample_rate;
+		} else if (sr_hint == 14) {
+			h[n++] = (uint8_t)((P.sample_rate / 10) >> 8);
+			h[n++] = (uint8_t)(P.sample_rate / 10);
+		}
+		uint8_t crc = 0;  // FLAC__crc8 (crc.c:124)
+		for (uint32_t i = 0; i < n; i++)
+			crc = c_crc8_table[crc ^ h[i]];
+		h[n++] = crc;
+		if (tid == 0)
+			for (uint32_t i = 0; i < n; i++)
+				emit_bits(S, 8 * i, 8, h[i]);
+		bitpos = 8 * n;
+	}
+	__syncthreads();
+
+	// ---- subframes in written order (stream_encoder.c:3091-3151) ----
+	for (uint32_t c = 0; c < P.channels; c++) {
+		uint32_t sig = c;
+		if (ca == 1 && c == 1) sig = P.channels + 1;       // left, side
+		else if (ca == 2 && c == 0) sig = P.channels + 1;  // side, right
+		else if (ca == 3) sig = P.channels + c;            // mid, side
+		const FaPlan *pl = plans + (size_t)f * P.nsignals + sig;
+		const FaSubStat st = stats[(size_t)f * P.nsignals + sig];
+		const uint32_t type = pl->type, order = pl->order, sbps = st.bps, wasted = st.wasted;
+		const uint32_t precision = pl->precision, po = pl->part_order, rice2 = pl->rice2, mode = pl->wide;
+		const int shift = pl->shift;
+		S.params[tid] = pl->params[tid];
+		if (tid < FA_MAX_ORDER)
+			S.q[tid] = pl->q[tid];
+		__syncthreads();
+
+		// FLAC__subframe_add_* (stream_encoder_framing.c:366-479): type byte, wasted-bits unary
+		uint32_t typebits;
+		switch (type) {
+		case FA_SUB_CONSTANT: typebits = 0x00; break;
+		case FA_SUB_VERBATIM: typebits = 0x02; break;
+		case FA_SUB_FIXED: typebits = 0x10 | (order << 1); break;
+		default: typebits = 0x40 | ((order - 1) << 1); break;
+		}
+		uint32_t pos = bitpos;
+		if (tid == 0) {
+			emit_bits(S, pos, 8, typebits | (wasted ? 1u : 0u));
+			if (wasted)
+				emit_bits(S, pos + 8 + wasted - 1, 1, 1);
+		}
+		pos += 8 + wasted;
+		if (type == FA_SUB_CONSTANT) {
+			if (tid == 0)
+				emit_bits(S, pos, sbps, (uint32_t)pl->constant);
+			pos += sbps;
+			__syncthreads();
+			bitpos = pos;
+			continue;
+		}
+		uint32_t plen = 0, psize = bsf, first_code_sample = 0, code_kind = 0;  // code_kind 0: verbatim fields, 1: Rice codes
+		if (type != FA_SUB_VERBATIM) {
+			// warm-up samples, LPC parameters, entropy coding method header
+			if (tid < order) {
+				const int32_t smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + tid, sig) >> wasted;
+				emit_bits(S, pos + tid * sbps, sbps, (uint32_t)smp);
+			}
+			pos += order * sbps;
+			if (type == FA_SUB_LPC) {
+				if (tid == 0) {
+					emit_bits(S, pos, 4, precision - 1);
+					emit_bits(S, pos + 4, 5, (uint32_t)shift);
+				}
+				pos += 9;
+				if (tid < order)
+					emit_bits(S, pos + tid * precision, precision, (uint32_t)S.q[tid]);
+				pos += order * precision;
+			}
+			if (tid == 0) {
+				emit_bits(S, pos, 2, rice2 ? 1u : 0u);
+				emit_bits(S, pos + 2, 4, po);
+			}
+			pos += 6;
+			plen = rice2 ? 5 : 4;
+			psize = bsf >> po;
+			first_code_sample = order;
+			code_kind = 1;
+		}
+		__syncthreads();
+
+		// ---- per-sample codes, tile by tile ----
+		uint32_t tile_start_bit = pos;
+		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
+			stage_tile<HIST>(T.v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, sig, wasted, tile * FA_TILE);
+			__syncthreads();
+			const int32_t base = (int32_t)(tile * FA_TILE + tid * FA_CHUNK);
+			int32_t res[FA_CHUNK];
+			uint32_t nbits = 0;
+			const bool have = (uint32_t)base < bsf;
+			if (have) {
+				int32_t d[HIST + FA_CHUNK];
+				load_chunk_lds<HIST>(d, T.v);
+				if (type == FA_SUB_VERBATIM) {
+#pragma unroll
+					for (int i = 0; i < FA_CHUNK; i++)
+						res[i] = d[HIST + i];
+				} else if (type == FA_SUB_FIXED)
+					fixed_residual16<HIST>(d, order, res);
+				else
+					lpc_residual16_any<HIST, NARROW>(d, S.q, order, shift, (int)mode, res);
+				uint32_t part = (uint32_t)base / psize;
+				uint32_t next = (part + 1) * psize;
+#pragma unroll
+				for (int i = 0; i < FA_CHUNK; i++) {
+					const uint32_t idx = (uint32_t)base + i;
+					if (idx == next) {
+						part++;
+						next += psize;
+					}
+					if (idx >= first_code_sample && idx < bsf) {
+						if (code_kind == 0)
+							nbits += sbps;
+						else {
+							const uint32_t k = S.params[part];
+							const uint32_t uz = ((uint32_t)res[i] << 1) ^ (uint32_t)(res[i] >> 31);
+							nbits += (uz >> k) + 1 + k;
+							if (idx == first_code_sample || idx == part * psize)
+								nbits += plen;
+						}
+					}
+				}
+			}
+			uint32_t tile_bits;
+			const uint32_t my_start = tile_start_bit + block_exclusive_scan(S, nbits, &tile_bits);
+			const uint32_t tile_end_bit = tile_start_bit + tile_bits;
+			drain(S, slot, slot_words, tile_end_bit, [&]() {
+				if (!have)
+					return;
+				uint32_t p = my_start;
+				uint32_t part = (uint32_t)base / psize;
+				uint32_t next = (part + 1) * psize;
+#pragma unroll
+				for (int i = 0; i < FA_CHUNK; i++) {
+					const uint32_t idx = (uint32_t)base + i;
+					if (idx == next) {
+						part++;
+						next += psize;
+					}
+					if (idx >= first_code_sample && idx < bsf) {
+						if (code_kind == 0) {
+							emit_bits(S, p, sbps, (uint32_t)res[i]);
+							p += sbps;
+						} else {
+							const uint32_t k = S.params[part];
+							if (idx == first_code_sample || idx == part * psize) {
+								emit_bits(S, p, plen, k);
+								p += plen;
+							}
+							// FLAC__bitwriter_write_rice_signed_block (bitwriter.c:544)
+							const uint32_t uz = ((uint32_t)res[i] << 1) ^ (uint32_t)(res[i] >> 31);
+							const uint32_t msbs = uz >> k;
+							emit_bits(S, p + msbs, k + 1, (1u << k) | (uz & ((1u << k) - 1u)));
+							p += msbs + 1 + k;
+						}
+					}
+				}
+			});
+			tile_start_bit = tile_end_bit;
+		}
+		bitpos = tile_start_bit;
+		__syncthreads();
+	}
+
+	// ---- zero padding, CRC-16 over everything so far (stream_encoder.c:2885-2900), final flush ----
+	const uint32_t nbytes = (bitpos + 7) >> 3;
+	{
+		const uint32_t bw = S.base_word;
+		const uint32_t tail_bytes = nbytes - bw * 4;
+		const uint32_t c = window_crc16(S, tail_bytes);
+		if (tid == 0) {
+			const uint32_t crc = gf16_mul(S.frame_crc, gf16_xpow8(tail_bytes)) ^ c;
+			emit_bits(S, nbytes * 8, 16, crc);
+		}
+		__syncthreads();
+		const uint32_t total_words = (nbytes + 2 + 3) / 4;
+		flush_window(S, slot, slot_words, total_words - bw, false, false);
+	}
+	if (tid == 0) {
+		frame_bytes[f] = nbytes + 2;
+		if (S.error)
+			atomicOr(errflag, 1u);
+	}
+}
+
+void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st)
+{
+	const dim3 grid(B.nframes), block(FA_THREADS);
+#define PACK_LAUNCH(H, N) hipLaunchKernelGGL((k_pack<H, N>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag)
+	const bool narrow = fa_narrow_only(P);
+	switch (fa_hist_class(P)) {
+	case 4: PACK_LAUNCH(4, true); break;
+	case 12: if (narrow) PACK_LAUNCH(12, true); else PACK_LAUNCH(12, false); break;
+	default: if (narrow) PACK_LAUNCH(32, true); else PACK_LAUNCH(32, false); break;
+	}
+#undef PACK_LAUNCH
+}

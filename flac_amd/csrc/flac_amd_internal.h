@@ -39,6 +39,8 @@ struct FaBatch {
 	uint32_t first_frame;
 	uint32_t sample_bytes;        // 2, 3 or 4
 	uint32_t loose_carry;         // assignment of the leader frame preceding this batch
+	uint32_t pairs;               // 16-bit stereo on a 4-byte boundary: one 32-bit load per wide sample
+	uint32_t pad;
 };
 
 // Per (frame, signal) statistics from the analysis pass.
