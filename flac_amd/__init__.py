@@ -5,6 +5,7 @@ package without the built library, or using it on a machine without an AMD GPU, 
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +49,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FlacAmdError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(or make -C flac_amd/csrc)" % LIB_PATH)
+        # PyTorch ships its own HIP runtime; when both are to live in one process torch's has to be
+        # the one that gets loaded, or whichever initialises second finds no device.
+        if "torch" not in sys.modules and not os.environ.get("FLAC_AMD_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.flacamd_last_error.restype = C.c_char_p
         _lib.flacamd_version.restype = C.c_char_p

@@ -326,7 +326,8 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	if (P.max_lpc_order > 0)
 		fa_launch_lpc(P, B, e->stats, e->autoc, e->cands, e->coefs, st);
 	STAGE_MARK();
-	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, st);
+	// FLAC_AMD_STAMPS: per-workgroup cycle stamps of k_search land in the (by now consumed) autocorrelation buffer
+	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, getenv("FLAC_AMD_STAMPS") ? (unsigned long long *)e->autoc : nullptr, st);
 	STAGE_MARK();
 	fa_launch_decide(P, B, e->plans, e->assign, e->errflag + 1, st);
 	STAGE_MARK();

@@ -35,25 +35,46 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 	__shared__ int32_t stage[ST_WORDS(4)];
 
 	// pass 1: OR of all samples (wasted bits) and whether they are all equal; the first tile stays
-	// staged (unshifted) for pass 2
-	const int32_t first = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start, s);
+	// staged (unshifted) for pass 2.  Loads are issued a tile at a time, back to back.
+	constexpr uint32_t HP = ST_HP(4);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	const SigAccess acc = sig_access(P.channels, B.sample_bytes, B.pairs, s);
+	int32_t first;
 	uint32_t orv = 0, ne = 0;
 	{
-		constexpr uint32_t HP = ST_HP(4);
-		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
-		for (uint32_t j = tid; j < n0; j += FA_THREADS) {
-			int32_t v = 0;
-			if (j >= HP && j - HP < bsf) {
-				v = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + (j - HP), s);
-				orv |= (uint32_t)v;
-				ne |= (uint32_t)(v != first);
-			}
-			stage[j + (j >> 4)] = v;
+		uint64_t wide[NIT + 1];
+		int32_t v[NIT + 1];
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			int32_t idx = (int32_t)j - (int32_t)HP;
+			idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+			wide[i] = frame_start + (uint32_t)idx;
 		}
-		for (uint32_t i = FA_TILE + tid; i < bsf; i += FA_THREADS) {
-			const int32_t x = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + i, s);
+		wide[NIT] = frame_start;
+		load_signal_block<(int)NIT + 1>(v, pcm, acc, wide);
+		first = v[NIT];
+		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			const bool inside = j >= HP && j - HP < bsf;
+			const int32_t x = inside ? v[i] : 0;
 			orv |= (uint32_t)x;
-			ne |= (uint32_t)(x != first);
+			ne |= (uint32_t)(inside && x != first);
+			if (j < n0)
+				stage[j + (j >> 4)] = x;
+		}
+	}
+	for (uint32_t t0 = FA_TILE; t0 < bsf; t0 += FA_TILE) {
+		int32_t v[NIT];
+		stage_load<4>(v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, t0);
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			const bool inside = j >= HP && t0 + j - HP < bsf;
+			orv |= inside ? (uint32_t)v[i] : 0u;
+			ne |= (uint32_t)(inside && v[i] != first);
 		}
 	}
 	orv = wave_or(orv);

@@ -81,9 +81,101 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
 // Stage samples [tile_base - ST_HP, tile_base + tile_len16) of signal s, shifted right by `wasted`;
 // positions outside the frame read as 0.  tile_len16 = samples of the tile in the frame, rounded up
 // to whole rows.
+// How a signal is formed from the PCM buffer, resolved once per workgroup so that the loads of a
+// whole block of samples can be issued back to back without branches in between.
+struct SigAccess {
+	uint32_t fmt;     // 0: 16-bit stereo pairs in one dword, 2 / 3 / 4: bytes per sample
+	uint32_t kind;    // 0 a channel, 1 mid, 2 side
+	uint32_t ca, cb;  // the channel(s) read
+	uint32_t channels;
+};
+
+__device__ __forceinline__ SigAccess sig_access(uint32_t channels, uint32_t sample_bytes, uint32_t pairs, uint32_t s)
+{
+	SigAccess a;
+	a.fmt = pairs ? 0 : sample_bytes;
+	a.kind = s < channels ? 0 : (s == channels ? 1 : 2);
+	a.ca = a.kind ? 0 : s;
+	a.cb = a.kind ? 1 : s;
+	a.channels = channels;
+	return a;
+}
+
+__device__ __forceinline__ int32_t sig_combine(uint32_t kind, int32_t x, int32_t y) { return kind == 0 ? x : kind == 1 ? ((x + y) >> 1) : (x - y); }
+
+// v[i] = signal value of wide sample wide[i], for N samples; one branch on the format, none per sample
+template <int N>
+__device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *pcm, const SigAccess &a, const uint64_t (&wide)[N])
+{
+	if (a.fmt == 0) {
+		uint32_t w[N];
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			w[i] = ((const uint32_t *)pcm)[wide[i]];
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			const int32_t l = (int32_t)(int16_t)(w[i] & 0xffff), r = (int32_t)w[i] >> 16;
+			v[i] = a.kind == 0 ? (a.ca ? r : l) : a.kind == 1 ? ((l + r) >> 1) : (l - r);
+		}
+	} else if (a.fmt == 2) {
+		int32_t x[N], y[N];
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			x[i] = ((const int16_t *)pcm)[wide[i] * a.channels + a.ca];
+			y[i] = ((const int16_t *)pcm)[wide[i] * a.channels + a.cb];
+		}
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			v[i] = sig_combine(a.kind, x[i], y[i]);
+	} else if (a.fmt == 4) {
+		int32_t x[N], y[N];
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			x[i] = ((const int32_t *)pcm)[wide[i] * a.channels + a.ca];
+			y[i] = ((const int32_t *)pcm)[wide[i] * a.channels + a.cb];
+		}
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			v[i] = sig_combine(a.kind, x[i], y[i]);
+	} else {
+		uint32_t x0[N], x1[N], y0[N], y1[N];
+		int32_t x2[N], y2[N];
+#pragma unroll
+		for (int i = 0; i < N; i++) {
+			const uint8_t *px = (const uint8_t *)pcm + (wide[i] * a.channels + a.ca) * 3;
+			const uint8_t *py = (const uint8_t *)pcm + (wide[i] * a.channels + a.cb) * 3;
+			x0[i] = px[0]; x1[i] = px[1]; x2[i] = (int8_t)px[2];
+			y0[i] = py[0]; y1[i] = py[1]; y2[i] = (int8_t)py[2];
+		}
+#pragma unroll
+		for (int i = 0; i < N; i++)
+			v[i] = sig_combine(a.kind, (int32_t)(x0[i] | (x1[i] << 8) | ((uint32_t)x2[i] << 16)), (int32_t)(y0[i] | (y1[i] << 8) | ((uint32_t)y2[i] << 16)));
+	}
+}
+
+// The two halves of staging: all loads first (raw values at clamped, always valid positions), the
+// LDS stores later, so that other work can be placed between them.
 template <int HIST>
-__device__ __forceinline__ void stage_tile(int32_t *lds, const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs,
-                                           uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t wasted, uint32_t tile_base)
+__device__ __forceinline__ void stage_load(int32_t (&v)[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS], const void *pcm, uint32_t channels,
+                                           uint32_t sample_bytes, uint32_t pairs, uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t tile_base)
+{
+	constexpr uint32_t HP = ST_HP(HIST);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	const SigAccess a = sig_access(channels, sample_bytes, pairs, s);
+	uint64_t wide[NIT];
+#pragma unroll
+	for (uint32_t i = 0; i < NIT; i++) {
+		const uint32_t j = threadIdx.x + i * FA_THREADS;
+		int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
+		idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+		wide[i] = frame_start + (uint32_t)idx;
+	}
+	load_signal_block<(int)NIT>(v, pcm, a, wide);
+}
+
+template <int HIST>
+__device__ __forceinline__ void stage_store(int32_t *lds, const int32_t (&v)[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS], uint32_t bsf,
+                                            uint32_t wasted, uint32_t tile_base)
 {
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
@@ -91,23 +183,23 @@ __device__ __forceinline__ void stage_tile(int32_t *lds, const void *pcm, uint32
 	if (tile_len > FA_TILE)
 		tile_len = FA_TILE;
 	const uint32_t n = HP + ((tile_len + 15) & ~15u);
-	// all loads are issued before the first store, at clamped (always valid) positions
-	int32_t v[NIT];
 #pragma unroll
 	for (uint32_t i = 0; i < NIT; i++) {
 		const uint32_t j = threadIdx.x + i * FA_THREADS;
-		int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
+		const int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
 		const bool inside = idx >= 0 && (uint32_t)idx < bsf;
-		idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
-		const int32_t x = fetch_signal(pcm, channels, sample_bytes, pairs, frame_start + (uint32_t)idx, s);
-		v[i] = inside ? (x >> wasted) : 0;
-	}
-#pragma unroll
-	for (uint32_t i = 0; i < NIT; i++) {
-		const uint32_t j = threadIdx.x + i * FA_THREADS;
 		if (j < n)
-			lds[j + (j >> 4)] = v[i];
+			lds[j + (j >> 4)] = inside ? (v[i] >> wasted) : 0;
 	}
+}
+
+template <int HIST>
+__device__ __forceinline__ void stage_tile(int32_t *lds, const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs,
+                                           uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t wasted, uint32_t tile_base)
+{
+	int32_t v[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS];
+	stage_load<HIST>(v, pcm, channels, sample_bytes, pairs, frame_start, bsf, s, tile_base);
+	stage_store<HIST>(lds, v, bsf, wasted, tile_base);
 }
 
 // d[k] = sample (16 t - HIST + k) of the staged tile, k = 0 .. HIST + 15
@@ -178,15 +270,16 @@ __device__ __forceinline__ void fixed_residual16(const int32_t (&d)[HIST + FA_CH
 	}
 }
 
-// FLAC__lpc_compute_residual_from_qlp_coefficients (lpc.c:265, int32 sum that wraps) and _wide
-// (lpc.c:531, int64 sum).  MODE 0: 24x24-bit multiplies (operands known to fit), wrapping int32
-// sum.  MODE 1: int64 sum truncated to int32 before the shift (== the wrapping int32 sum).
-// MODE 2: int64 sum, shifted, then truncated.  `order` and q[] are the same for every lane: taps
-// are added one at a time under a scalar branch, with the coefficient in a scalar register, so one
-// copy of the code serves every order up to MAXORDER.
-template <int HIST, int MAXORDER, int MODE>
-__device__ __forceinline__ void lpc_residual16_taps(const int32_t (&d)[HIST + FA_CHUNK], const int32_t *__restrict__ q, uint32_t order, int shift,
-                                                    int32_t (&res)[FA_CHUNK])
+// The prediction of FLAC__lpc_compute_residual_from_qlp_coefficients (lpc.c:265, int32 sum that
+// wraps) and _wide (lpc.c:531, int64 sum) for the thread's 16 samples.  MODE 0: 24x24-bit
+// multiplies (operands known to fit), wrapping int32 sum.  MODE 1: int64 sum truncated to int32
+// before the shift (== the wrapping int32 sum).  MODE 2: int64 sum, shifted, then truncated.
+// `order` and q[] are the same for every lane: taps are added one at a time under a scalar branch,
+// with the coefficient in a scalar register, so one copy of the code serves every order up to
+// MAXORDER.
+template <int HIST, int MAXORDER, int MODE, typename Q>
+__device__ __forceinline__ void lpc_pred16_taps(const int32_t (&d)[HIST + FA_CHUNK], const Q &q, uint32_t order, int shift,
+                                                int32_t (&pred)[FA_CHUNK])
 {
 	if (MODE == 0) {
 		int32_t sum[FA_CHUNK];
@@ -204,7 +297,7 @@ __device__ __forceinline__ void lpc_residual16_taps(const int32_t (&d)[HIST + FA
 		}
 #pragma unroll
 		for (int i = 0; i < FA_CHUNK; i++)
-			res[i] = (int32_t)((uint32_t)d[HIST + i] - (uint32_t)(sum[i] >> shift));
+			pred[i] = sum[i] >> shift;
 	} else {
 		int64_t sum[FA_CHUNK];
 #pragma unroll
@@ -220,25 +313,70 @@ __device__ __forceinline__ void lpc_residual16_taps(const int32_t (&d)[HIST + FA
 			}
 		}
 #pragma unroll
-		for (int i = 0; i < FA_CHUNK; i++) {
-			const int32_t pred = (MODE == 1) ? ((int32_t)sum[i] >> shift) : (int32_t)(sum[i] >> shift);
-			res[i] = (int32_t)((uint32_t)d[HIST + i] - (uint32_t)pred);
-		}
+		for (int i = 0; i < FA_CHUNK; i++)
+			pred[i] = (MODE == 1) ? ((int32_t)sum[i] >> shift) : (int32_t)(sum[i] >> shift);
 	}
 }
 
+// The same prediction when samples and coefficients fit 16 bits: two taps per v_dot2_i32_i16.
+// P[k] holds samples (16 t - HIST + k) and (.. + k + 1) of the tile in its low and high half;
+// qp[jj] holds coefficient 2 jj + 1 in its low half and 2 jj in its high half (0 past the order).
+typedef short fa_short2 __attribute__((ext_vector_type(2)));
+
+template <int HIST, int MAXORDER, typename Q>
+__device__ __forceinline__ void lpc_pred16_dot2(const int32_t (&P)[HIST + FA_CHUNK - 1], const Q &qp, uint32_t order, int shift,
+                                                int32_t (&pred)[FA_CHUNK])
+{
+	int32_t sum[FA_CHUNK];
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++)
+		sum[i] = 0;
+#pragma unroll
+	for (int jj = 0; jj < (MAXORDER + 1) / 2; jj++) {
+		if ((uint32_t)(2 * jj) < order) {
+			const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[jj]);
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				sum[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, P[HIST + i - 2 - 2 * jj]), __builtin_bit_cast(fa_short2, qv), sum[i], false);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++)
+		pred[i] = sum[i] >> shift;
+}
+
 // NARROW: the caller knows every candidate of the stream is MODE 0 (see fa_narrow_only)
+template <int HIST, bool NARROW, typename Q>
+__device__ __forceinline__ void lpc_pred16_any(const int32_t (&d)[HIST + FA_CHUNK], const Q &q, uint32_t order, int shift, int mode,
+                                               int32_t (&pred)[FA_CHUNK])
+{
+	constexpr int MAXORDER = HIST < FA_MAX_ORDER ? HIST : FA_MAX_ORDER;
+	if (NARROW || mode == 0)
+		lpc_pred16_taps<HIST, MAXORDER, 0>(d, q, order, shift, pred);
+	else if (mode == 1)
+		lpc_pred16_taps<HIST, MAXORDER, 1>(d, q, order, shift, pred);
+	else
+		lpc_pred16_taps<HIST, MAXORDER, 2>(d, q, order, shift, pred);
+}
+
 template <int HIST, bool NARROW>
 __device__ __forceinline__ void lpc_residual16_any(const int32_t (&d)[HIST + FA_CHUNK], const int32_t *q, uint32_t order, int shift, int mode,
                                                    int32_t (&res)[FA_CHUNK])
 {
-	constexpr int MAXORDER = HIST < FA_MAX_ORDER ? HIST : FA_MAX_ORDER;
-	if (NARROW || mode == 0)
-		lpc_residual16_taps<HIST, MAXORDER, 0>(d, q, order, shift, res);
-	else if (mode == 1)
-		lpc_residual16_taps<HIST, MAXORDER, 1>(d, q, order, shift, res);
-	else
-		lpc_residual16_taps<HIST, MAXORDER, 2>(d, q, order, shift, res);
+	int32_t pred[FA_CHUNK];
+	lpc_pred16_any<HIST, NARROW>(d, q, order, shift, mode, pred);
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++)
+		res[i] = (int32_t)((uint32_t)d[HIST + i] - (uint32_t)pred[i]);
+}
+
+// acc + |x - 2^31| for x = (value ^ 0x80000000): the absolute value of a signed `value`, added up
+// (v_sad_u32 takes the unsigned absolute difference)
+__device__ __forceinline__ uint32_t sad_biased(uint32_t x, uint32_t bias, uint32_t acc)
+{
+	uint32_t r;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(bias), "v"(acc));
+	return r;
 }
 
 // which arithmetic the residual of an LPC candidate needs

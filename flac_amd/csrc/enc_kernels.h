@@ -13,7 +13,7 @@ void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, co
 void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stats, const float *autoc, FaLpcCand *cands, int32_t *coefs,
                    hipStream_t st);
 void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
-                      const int32_t *coefs, FaPlan *plans, hipStream_t st);
+                      const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st);
 void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st);
 void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
                     uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st);

@@ -5,12 +5,20 @@
 #include "enc_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
-// k_search: process_subframe_ (stream_encoder.c:3164) for one (frame, signal): every candidate's
-// residual is produced in registers, only |residual| partition sums go to LDS, and
-// find_best_partition_order_ / set_partitioned_rice_ (stream_encoder.c:3666,3943) run on those.
+// k_search: process_subframe_ (stream_encoder.c:3164) for one (frame, signal).
+//
+// Every candidate predictor (the fixed ones are coefficient rows like the LPC ones) is run over
+// the frame with the samples in registers; only the |residual| sums of the finest Rice partitions
+// go to LDS.  find_best_partition_order_ / set_partitioned_rice_ (stream_encoder.c:3666,3943) then
+// work from those sums: the sum of a coarser partition is the sum of the finest ones it covers.
+//
+// A workgroup's life is a chain of dependent steps, so everything it needs from global memory (the
+// frame's samples, the candidate list, the coefficients) is requested at entry in one go.
 // ---------------------------------------------------------------------------------------------
-#define SR_SUM_BYTES 32768
 #define SR_MAXGROUP 32
+#define SR_MAXSUM_BYTES 32768
+#define SR_PRE_CANDS 256   // candidate slots fetched at entry
+#define SR_PRE_COEFS 1024  // coefficients fetched at entry
 
 struct SrCand {
 	uint32_t kind;      // FA_SUB_FIXED / FA_SUB_LPC
@@ -26,78 +34,144 @@ struct SrCand {
 	uint32_t best_po, best_rbits, total_bits;
 };
 
-// Add |res[i]| of the chunk's samples that lie in [order, bsf) to the candidate's partition sums
-// (the lowest level of precompute_partition_info_sums_, stream_encoder.c:3774).  fast: every
-// |res[i]| of this candidate is known to be below 2^27, so a chunk's sum fits 32 bits.
+// Add |res[i]| of the chunk's samples that lie in [order, bsf) to the candidate's finest-partition
+// sums (the lowest level of precompute_partition_info_sums_, stream_encoder.c:3774).
 __device__ __forceinline__ void accumulate_chunk(const int32_t (&res)[FA_CHUNK], uint64_t *gs, uint32_t base, uint32_t order, uint32_t bsf,
-                                                 uint32_t psize, uint32_t fast)
+                                                 uint32_t psize)
 {
-	if ((psize & (FA_CHUNK - 1)) == 0) {
-		// the whole chunk lies in one partition
-		uint64_t t;
-		if (fast) {
-			uint32_t t32 = 0;
-			if (base >= order && base + FA_CHUNK <= bsf) {
+	uint32_t part = base / psize;
+	uint32_t next = (part + 1) * psize;
+	uint64_t t = 0;
 #pragma unroll
-				for (int i = 0; i < FA_CHUNK; i++)
-					t32 += abs32(res[i]);
-			} else {
-#pragma unroll
-				for (int i = 0; i < FA_CHUNK; i++) {
-					const uint32_t idx = base + i;
-					if (idx >= order && idx < bsf)
-						t32 += abs32(res[i]);
-				}
-			}
-			t = t32;
-		} else {
+	for (int i = 0; i < FA_CHUNK; i++) {
+		const uint32_t idx = base + i;
+		if (idx == next) {
+			if (t) atomicAdd((unsigned long long *)&gs[part], (unsigned long long)t);
 			t = 0;
-#pragma unroll
-			for (int i = 0; i < FA_CHUNK; i++) {
-				const uint32_t idx = base + i;
-				if (idx >= order && idx < bsf)
-					t += abs32(res[i]);
-			}
+			part++;
+			next += psize;
 		}
-		atomicAdd((unsigned long long *)&gs[base / psize], (unsigned long long)t);
+		if (idx >= order && idx < bsf)
+			t += abs32(res[i]);
+	}
+	if (t) atomicAdd((unsigned long long *)&gs[part], (unsigned long long)t);
+}
+
+// The same from the biased samples db[i] = sample ^ 2^31 and the predictions: the biased residual
+// (sample ^ 2^31) - prediction = residual ^ 2^31 feeds v_sad_u32 directly.  quick: the chunk lies
+// inside the frame and inside one partition and its sum fits 32 bits; warm-up samples (index <
+// order, the first thread or two) are taken back out afterwards.
+__device__ __forceinline__ void accumulate_biased(const uint32_t (&db)[FA_CHUNK], const int32_t (&pred)[FA_CHUNK], uint64_t *gs, uint32_t base,
+                                                  uint32_t order, uint32_t bsf, uint32_t psize, bool quick, uint32_t bias)
+{
+	if (quick) {
+		uint32_t t32 = 0;
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			t32 = sad_biased(db[i] - (uint32_t)pred[i], bias, t32);
+		if (base < order) {
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				if (base + i < order)
+					t32 -= abs32((int32_t)((db[i] - (uint32_t)pred[i]) ^ bias));
+		}
+		atomicAdd((unsigned long long *)&gs[base / psize], (unsigned long long)t32);
 	} else {
-		uint32_t part = base / psize;
-		uint32_t next = (part + 1) * psize;
-		uint64_t t = 0;
+		int32_t res[FA_CHUNK];
 #pragma unroll
-		for (int i = 0; i < FA_CHUNK; i++) {
-			const uint32_t idx = base + i;
-			if (idx == next) {
-				if (t) atomicAdd((unsigned long long *)&gs[part], (unsigned long long)t);
-				t = 0;
-				part++;
-				next += psize;
-			}
-			if (idx >= order && idx < bsf)
-				t += abs32(res[i]);
-		}
-		if (t) atomicAdd((unsigned long long *)&gs[part], (unsigned long long)t);
+		for (int i = 0; i < FA_CHUNK; i++)
+			res[i] = (int32_t)((db[i] - (uint32_t)pred[i]) ^ bias);
+		accumulate_chunk(res, gs, base, order, bsf, psize);
 	}
 }
 
-template <int HIST, bool NARROW>
-__global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
-                                                       const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans, uint32_t sum_bytes)
+// LDS carve-up, computed the same way on the host (for the size) and in the kernel.
+struct SrLayout {
+	uint32_t sums, stage, pbits, gc, best, ctl, cq, cqp, gp, lcand, allq, total;
+};
+
+__host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage_bytes, uint32_t alias, uint32_t ncmax, uint32_t qstride,
+                                               uint32_t npre_cands, uint32_t npre_coefs)
 {
+	SrLayout L;
+	uint32_t o = 0;
+	L.sums = o;
+	if (alias) {
+		L.stage = o;
+		o += sum_bytes > stage_bytes ? sum_bytes : stage_bytes;
+	} else {
+		o += sum_bytes;
+		L.stage = o;
+		o += stage_bytes;
+	}
+	o = (o + 15) & ~15u;
+	L.pbits = o; o += ncmax * 16 * 4;
+	L.gc = o; o += ncmax * (uint32_t)sizeof(SrCand);
+	L.best = o; o += (uint32_t)sizeof(FaPlan);
+	L.ctl = o; o += 16 * 4;
+	L.cq = o; o += ncmax * qstride * 4;
+	o = (o + 15) & ~15u;
+	L.cqp = o; o += ncmax * ((qstride + 1) / 2) * 4;
+	o = (o + 15) & ~15u;
+	L.gp = o; o += ncmax * 8 * 4;
+	L.lcand = o; o += npre_cands * (uint32_t)sizeof(FaLpcCand);
+	L.allq = o; o += npre_coefs * 4;
+	L.total = (o + 15) & ~15u;
+	return L;
+}
+
+#ifndef SEARCH_WAVES
+#define SEARCH_WAVES 3
+#endif
+
+template <int HIST, bool NARROW>
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SEARCH_WAVES, SEARCH_WAVES)))
+void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans,
+              uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps)
+{
+// debugging aid: the first time thread 0 passes point k, the shader clock goes to stamps[block][k]
+#define STAMP(k) do { if (stamps && threadIdx.x == 0 && first_pass) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+	bool first_pass = true;
+	constexpr int MAXORDER = HIST < FA_MAX_ORDER ? HIST : FA_MAX_ORDER;   // largest predictor order this kernel runs
+	constexpr int NQP = (MAXORDER + 1) / 2;
+	constexpr uint32_t NIT = (ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint64_t *sums = (uint64_t *)smem;                                  // [group][2 * PF]
-	uint32_t *pbits = (uint32_t *)(smem + sum_bytes);                // [group][16]
-	SrCand *gc = (SrCand *)(pbits + SR_MAXGROUP * 16);                  // [group]
-	FaPlan *best = (FaPlan *)(gc + SR_MAXGROUP);
-	uint32_t *ctl = (uint32_t *)(best + 1);                             // [0]=ngroup [1]=cursor [2]=best_changed_to [3]=rice2 flag
-	int32_t *cq = (int32_t *)(ctl + 16);                                // [group][FA_MAX_ORDER] quantised coefficients
-	int32_t *stage = cq + SR_MAXGROUP * FA_MAX_ORDER;                   // the staged signal tile
+	const uint32_t ncoef_all = P.ncand * P.max_lpc_order;
+	const uint32_t npre_cands = umin32(P.ncand, SR_PRE_CANDS), npre_coefs = umin32(ncoef_all, SR_PRE_COEFS);
+	const SrLayout L = sr_layout(sum_bytes, ST_WORDS(HIST) * 4, alias, ncmax, MAXORDER, npre_cands, npre_coefs);
+	uint64_t *sums = (uint64_t *)(smem + L.sums);       // [group][2 PF] partition sums: finest level first, then each coarser one
+	int32_t *stage = (int32_t *)(smem + L.stage);       // the staged signal tile
+	uint32_t *pbits = (uint32_t *)(smem + L.pbits);     // [group][16] residual bits per partition order
+	SrCand *gc = (SrCand *)(smem + L.gc);               // [group]
+	FaPlan *best = (FaPlan *)(smem + L.best);
+	uint32_t *ctl = (uint32_t *)(smem + L.ctl);         // [0]=group size [1]=cursor [2]=winner [3]=rice2 flag
+	int32_t *cq = (int32_t *)(smem + L.cq);             // [group][MAXORDER] quantised coefficients
+	int32_t *cqp = (int32_t *)(smem + L.cqp);           // [group][NQP] the same, two 16-bit taps per word
+	uint32_t *gp = (uint32_t *)(smem + L.gp);           // [group][4] order, shift, psize, fast | mode << 1
+	uint32_t *gq = gp + ncmax * 4;                      // [group][4] pmax | pmin << 8 | use32 << 16, order, seed
+	FaLpcCand *lcand = (FaLpcCand *)(smem + L.lcand);   // candidate slots fetched at entry
+	int32_t *allq = (int32_t *)(smem + L.allq);         // coefficients fetched at entry
 
 	const uint32_t task = blockIdx.x;
 	const uint32_t f = task / P.nsignals, s = task % P.nsignals;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
+	const FaLpcCand *my_cands = cands + (size_t)task * P.ncand;
+	const int32_t *my_coefs = coefs + (size_t)task * ncoef_all;
+
+	STAMP(0);
+	// ---- everything this workgroup reads from global memory, requested up front ----
+	FaLpcCand pre_c;
+	pre_c.valid = 0;
+	if (tid < npre_cands)
+		pre_c = my_cands[tid];
+	int32_t pre_q[SR_PRE_COEFS / FA_THREADS];
+#pragma unroll
+	for (uint32_t k = 0; k < SR_PRE_COEFS / FA_THREADS; k++)
+		pre_q[k] = (tid + k * FA_THREADS < npre_coefs) ? my_coefs[tid + k * FA_THREADS] : 0;
+	int32_t tile_v[NIT];
+	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, 0);
 	const FaSubStat st = stats[task];
 	const uint32_t sbps = st.bps, wasted = st.wasted;
 	const uint32_t hdr = 8 + wasted;
@@ -111,9 +185,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 	}
 	const uint32_t frame_min_po = umin32(P.min_po, frame_max_po);
 	const uint32_t PF = 1u << frame_max_po;
-	const uint32_t group_cap = umin32(SR_MAXGROUP, sum_bytes / (2 * PF * 8));
-	const FaLpcCand *my_cands = cands + (size_t)task * P.ncand;
-	const int32_t *my_coefs = coefs + (size_t)task * P.ncand * P.max_lpc_order;
+	const uint32_t group_cap = umin32(ncmax, sum_bytes / (2 * PF * 8));
+	const uint32_t ntiles = (bsf + FA_TILE - 1) / FA_TILE;
 
 	if (tid == 0) {
 		best->type = FA_SUB_VERBATIM;
@@ -138,10 +211,19 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 		}
 		ctl[1] = 0;
 	}
+	stage_store<HIST>(stage, tile_v, bsf, wasted, 0);
+	if (tid < npre_cands)
+		lcand[tid] = pre_c;
+#pragma unroll
+	for (uint32_t k = 0; k < SR_PRE_COEFS / FA_THREADS; k++)
+		if (tid + k * FA_THREADS < npre_coefs)
+			allq[tid + k * FA_THREADS] = pre_q[k];
 	__syncthreads();
+	STAMP(1);
 
 	const bool search = bsf >= 4 && !st.is_constant;
 	const uint32_t total_cands = 5 + P.ncand;
+	bool staged = true;   // the stage area holds tile 0
 	while (search) {
 		// ---- wave 0 gathers the next group of candidates, in the reference's trial order: lane i
 		// looks at candidate cursor + i, the takers are packed in order ----
@@ -157,7 +239,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 				c.slot = 0;
 				c.precision = 0;
 				c.shift = 0;
-				c.mode = 0;
+				c.mode = (uint32_t)lpc_mode(0, sbps);
 				c.hdr_bits = 0;
 				bool take = false;
 				if (my < 5) {
@@ -179,12 +261,17 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 						take = true;
 					}
 				} else if (my < total_cands) {
-					const FaLpcCand lc = my_cands[my - 5];
+					const uint32_t slot = my - 5;
+					FaLpcCand lc;
+					if (slot < npre_cands)
+						lc = lcand[slot];
+					else
+						lc = my_cands[slot];
 					if (lc.valid) {
 						c.kind = FA_SUB_LPC;
 						c.order = lc.order;
 						c.seed = lc.rice;
-						c.slot = my - 5;
+						c.slot = slot;
 						c.precision = lc.precision;
 						c.shift = lc.shift;
 						c.mode = (uint32_t)lpc_mode(lc.wide, sbps);
@@ -199,7 +286,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 				c.best_po = 0;
 				c.best_rbits = 0;
 				c.total_bits = 0;
-				c.fast = (c.kind == FA_SUB_FIXED && sbps <= 23) ? 1u : 0u;  // |4th difference| < 2^(sbps+3)
+				c.fast = 0;
 				const uint64_t takers = __ballot(take);
 				const uint32_t before = (uint32_t)__popcll(takers & ((1ull << tid) - 1ull));
 				const uint32_t room = group_cap - n;
@@ -222,154 +309,231 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 			}
 		}
 		__syncthreads();
+		STAMP(2);
 		const uint32_t ng = ctl[0];
 		if (ng == 0)
 			break;
-		for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
-			sums[e] = 0;
+		// ---- per-candidate tables: coefficients (plain and packed in pairs), loop parameters ----
+		// coefficient j of group member g; a fixed predictor of order o is the filter {1}, {2,-1},
+		// {3,-3,1}, {4,-6,4,-1} with shift 0 (fixed.c:352-388) and runs through the same code
+		auto coef = [&](uint32_t g, uint32_t j) -> int32_t {
+			const uint32_t o = gc[g].order;
+			if (j >= o)
+				return 0;
+			if (gc[g].kind == FA_SUB_LPC) {
+				const uint32_t at = gc[g].slot * P.max_lpc_order + j;
+				return at < npre_coefs ? allq[at] : my_coefs[at];
+			}
+			return j == 0 ? (int32_t)o : j == 1 ? (o == 2 ? -1 : o == 3 ? -3 : -6) : j == 2 ? (o == 3 ? 1 : 4) : -1;
+		};
+		for (uint32_t e = tid; e < ng * MAXORDER; e += FA_THREADS)
+			cq[e] = coef(e / MAXORDER, e % MAXORDER);
+		for (uint32_t e = tid; e < ng * NQP; e += FA_THREADS) {
+			const uint32_t g = e / NQP, jj = e % NQP;
+			const uint32_t q0 = (uint32_t)coef(g, 2 * jj), q1 = (uint32_t)coef(g, 2 * jj + 1);
+			cqp[e] = (int32_t)((q0 << 16) | (q1 & 0xffffu));
+		}
 		for (uint32_t e = tid; e < ng * 16; e += FA_THREADS)
 			pbits[e] = 0;
-		for (uint32_t e = tid; e < ng * FA_MAX_ORDER; e += FA_THREADS) {
-			const uint32_t g = e / FA_MAX_ORDER, j = e % FA_MAX_ORDER;
-			cq[e] = (gc[g].kind == FA_SUB_LPC && j < gc[g].order) ? my_coefs[(size_t)gc[g].slot * P.max_lpc_order + j] : 0;
+		if (tid >= 64 && tid - 64 < ng) {
+			const uint32_t g = tid - 64;
+			SrCand &c = gc[g];
+			// |prediction| <= (sum |q| * max |sample|) >> shift, |residual| <= |sample| + |prediction|
+			uint64_t sumq = 0;
+			for (uint32_t j = 0; j < c.order; j++)
+				sumq += abs32(coef(g, j));
+			const uint64_t bound = (1ull << (sbps - 1)) + ((sumq << (sbps - 1)) >> c.shift) + 1;
+			const uint32_t fast = (c.mode == 0 && bound < (1ull << 27)) ? 1u : 0u;
+			c.fast = fast;
+			gp[4 * g] = c.order;
+			gp[4 * g + 1] = (uint32_t)c.shift;
+			gp[4 * g + 2] = c.psize;
+			gp[4 * g + 3] = fast | (c.mode << 1);
+			gq[4 * g] = c.pmax | (c.pmin << 8) | (c.use32 << 16);
+			gq[4 * g + 1] = c.order;
+			gq[4 * g + 2] = c.seed;
+			gq[4 * g + 3] = 0;
 		}
-		__syncthreads();
-		if (tid < ng) {
-			SrCand &c = gc[tid];
-			if (c.kind == FA_SUB_LPC) {
-				// |prediction| <= (sum |q| * max |sample|) >> shift, |residual| <= |sample| + |prediction|
-				uint64_t sumq = 0;
-				for (uint32_t j = 0; j < c.order; j++)
-					sumq += abs32(cq[tid * FA_MAX_ORDER + j]);
-				const uint64_t bound = (1ull << (sbps - 1)) + ((sumq << (sbps - 1)) >> c.shift) + 1;
-				c.fast = (c.mode == 0 && bound < (1ull << 27)) ? 1u : 0u;
-			}
+		if (!alias) {
+			for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
+				sums[e] = 0;
 		}
-		if (tid == 64) {
-			uint32_t nf = 0;
-			while (nf < ng && gc[nf].kind == FA_SUB_FIXED)
-				nf++;
-			ctl[4] = nf;
-		}
+		STAMP(3);
 
 		// ---- residuals of every candidate of the group, tile by tile, all in registers ----
-		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
+		for (uint32_t tile = 0; tile < ntiles; tile++) {
+			if (!(tile == 0 && staged)) {
+				__syncthreads();
+				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, wasted, tile * FA_TILE);
+			}
 			__syncthreads();
-			stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, wasted, tile * FA_TILE);
-			__syncthreads();
-			const int32_t base = (int32_t)(tile * FA_TILE + tid * FA_CHUNK);
-			if ((uint32_t)base >= bsf)
-				continue;
+			staged = false;
+			const uint32_t base = tile * FA_TILE + tid * FA_CHUNK;
+			const bool have = base < bsf;
 			int32_t d[HIST + FA_CHUNK];
-			load_chunk_lds<HIST>(d, stage);
-			// fixed predictors (always the leading candidates of the first group): the order-o
-			// residual is the o-th difference (fixed.c:352), taken in place one order at a time
-			const uint32_t nfixed = __builtin_amdgcn_readfirstlane(ctl[4]);
-			if (nfixed) {
-				int32_t r[4 + FA_CHUNK];
-#pragma unroll
-				for (int k = 0; k < 4 + FA_CHUNK; k++)
-					r[k] = d[HIST - 4 + k];
-				uint32_t g = 0;
-#pragma unroll
-				for (uint32_t o = 0; o <= 4; o++) {
-					if (o > 0) {
-#pragma unroll
-						for (int k = 4 + FA_CHUNK - 1; k >= (int)o; k--)
-							r[k] = (int32_t)((uint32_t)r[k] - (uint32_t)r[k - 1]);
-					}
-					if (g < nfixed && __builtin_amdgcn_readfirstlane(gc[g].order) == o) {
-						int32_t res[FA_CHUNK];
-#pragma unroll
-						for (int i = 0; i < FA_CHUNK; i++)
-							res[i] = r[4 + i];
-						accumulate_chunk(res, sums + (size_t)g * 2 * PF, (uint32_t)base, o, bsf, __builtin_amdgcn_readfirstlane(gc[g].psize),
-						                 __builtin_amdgcn_readfirstlane(gc[g].fast));
-						g++;
-					}
-				}
+			if (have)
+				load_chunk_lds<HIST>(d, stage);
+			if (alias) {
+				// the sums take over the stage area once every thread holds its samples
+				__syncthreads();
+				for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
+					sums[e] = 0;
+				__syncthreads();
 			}
+			STAMP(4);
+			if (!have)
+				continue;
+			const uint32_t bias = 0x80000000u;
+			uint32_t db[FA_CHUNK];
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				db[i] = (uint32_t)d[HIST + i] ^ bias;
+			const bool chunk_inside = base + FA_CHUNK <= bsf;
+			// the next candidate's parameters and coefficients are fetched from LDS while the current
+			// one is computed; at the loop top they move to scalar registers
+			if (HIST >= 12 && sbps <= 16) {
+				// samples and coefficients fit 16 bits: two taps per instruction
+				int32_t Pk[HIST + FA_CHUNK - 1];
+#pragma unroll
+				for (int k = 0; k < HIST + FA_CHUNK - 1; k++)
+					Pk[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k + 1], (uint32_t)d[k], 0x05040100u);
+				uint32_t nxp[4];
+				int32_t nxq[NQP];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					nxp[k] = gp[k];
+#pragma unroll
+				for (int k = 0; k < NQP; k++)
+					nxq[k] = cqp[k];
 #pragma nounroll
-			for (uint32_t g = nfixed; g < ng; g++) {
-				const uint32_t order = __builtin_amdgcn_readfirstlane(gc[g].order);
-				const int shift = (int)__builtin_amdgcn_readfirstlane((uint32_t)gc[g].shift);
-				const int mode = (int)__builtin_amdgcn_readfirstlane(gc[g].mode);
-				int32_t res[FA_CHUNK];
-#ifdef EXP_FIXED12
-				lpc_residual16<HIST, 12, 0>(d, cq + g * FA_MAX_ORDER, shift, res);
-#else
-				lpc_residual16_any<HIST, NARROW>(d, cq + g * FA_MAX_ORDER, order, shift, mode, res);
-#endif
-				accumulate_chunk(res, sums + (size_t)g * 2 * PF, (uint32_t)base, order, bsf, __builtin_amdgcn_readfirstlane(gc[g].psize),
-				                 __builtin_amdgcn_readfirstlane(gc[g].fast));
+				for (uint32_t g = 0; g < ng; g++) {
+					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
+					const int shift = (int)__builtin_amdgcn_readfirstlane(nxp[1]);
+					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
+					const uint32_t fast = __builtin_amdgcn_readfirstlane(nxp[3]) & 1u;
+					int32_t qs[NQP];
+#pragma unroll
+					for (int k = 0; k < NQP; k++)
+						qs[k] = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxq[k]);
+					if (g + 1 < ng) {
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							nxp[k] = gp[4 * (g + 1) + k];
+#pragma unroll
+						for (int k = 0; k < NQP; k++)
+							nxq[k] = cqp[(g + 1) * NQP + k];
+					}
+					int32_t pred[FA_CHUNK];
+					lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
+					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
+					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias);
+				}
+			} else {
+				uint32_t nxp[4];
+				int32_t nxq[MAXORDER];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					nxp[k] = gp[k];
+#pragma unroll
+				for (int k = 0; k < MAXORDER; k++)
+					nxq[k] = cq[k];
+#pragma nounroll
+				for (uint32_t g = 0; g < ng; g++) {
+					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
+					const int shift = (int)__builtin_amdgcn_readfirstlane(nxp[1]);
+					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
+					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
+					const uint32_t fast = flags & 1u;
+					const int mode = (int)(flags >> 1);
+					int32_t qs[MAXORDER];
+#pragma unroll
+					for (int k = 0; k < MAXORDER; k++)
+						qs[k] = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxq[k]);
+					if (g + 1 < ng) {
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							nxp[k] = gp[4 * (g + 1) + k];
+#pragma unroll
+						for (int k = 0; k < MAXORDER; k++)
+							nxq[k] = cq[(g + 1) * MAXORDER + k];
+					}
+					int32_t pred[FA_CHUNK];
+					lpc_pred16_any<HIST, NARROW>(d, qs, order, shift, mode, pred);
+					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
+					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias);
+				}
 			}
 		}
+		STAMP(5);
 		__syncthreads();
+		STAMP(6);
 
-		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): truncate, then merge ----
-		for (uint32_t e = tid; e < ng * PF; e += FA_THREADS) {
-			const uint32_t g = e / PF, part = e % PF;
-			if (part < (1u << gc[g].pmax) && gc[g].use32)
-				sums[(size_t)g * 2 * PF + part] &= 0xffffffffull;
+		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): every finest sum, truncated to
+		// 32 bits where the reference's accumulator is that narrow (:3803-3833), is added into the
+		// partition above it at each coarser level.  The adds are LDS atomics nobody waits for. ----
+		const uint32_t fpo = frame_max_po;
+		for (uint32_t e = tid; e < (ng << fpo); e += FA_THREADS) {
+			const uint32_t g = e >> fpo, part = e & (PF - 1);
+			const uint4 q = *(const uint4 *)(gq + 4 * g);
+			const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
+			uint64_t *gs = sums + (size_t)g * 2 * PF;
+			if (part < (1u << pm)) {
+				uint64_t v = gs[part];
+				if (q.x >> 16) {
+					v &= 0xffffffffull;
+					gs[part] = v;
+				}
+				for (uint32_t lvl = pm; lvl-- > pmn;)
+					atomicAdd((unsigned long long *)&gs[(2u << pm) - (2u << lvl) + (part >> (pm - lvl))], (unsigned long long)v);
+			}
 		}
 		__syncthreads();
-		for (int lvl = (int)frame_max_po - 1; lvl >= 0; lvl--) {
-			for (uint32_t e = tid; e < ng * (1u << lvl); e += FA_THREADS) {
-				const uint32_t g = e >> lvl, part = e & ((1u << lvl) - 1);
-				const uint32_t pm = gc[g].pmax;
-				if ((uint32_t)lvl < pm && (uint32_t)lvl >= gc[g].pmin) {
-					uint64_t *gs = sums + (size_t)g * 2 * PF;
-					const uint32_t off_hi = (2u << pm) - (2u << (lvl + 1));
-					const uint32_t off_lo = (2u << pm) - (2u << lvl);
-					gs[off_lo + part] = gs[off_hi + 2 * part] + gs[off_hi + 2 * part + 1];
-				}
-			}
-			__syncthreads();
-		}
 		// ---- set_partitioned_rice_ (stream_encoder.c:3943) for every (candidate, order, partition) ----
-		for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS) {
-			const uint32_t g = e / (2 * PF), idx = e % (2 * PF);
-			const SrCand &c = gc[g];
-			const uint32_t span = 2u << c.pmax;
-			if (idx + 1 >= span)
-				continue;
-			const uint32_t r = span - idx;
-			const uint32_t po = ilog2u(r - 1);
-			if (po < c.pmin)
-				continue;
-			const uint32_t part = (2u << po) - r;
-			uint32_t n = bsf >> po;
-			if (part == 0)
-				n -= c.order;
+		for (uint32_t e = tid; e < (ng << (fpo + 1)); e += FA_THREADS) {
+			const uint32_t g = e >> (fpo + 1), idx = e & (2 * PF - 1);
+			const uint4 q = *(const uint4 *)(gq + 4 * g);
 			const uint64_t sm = sums[(size_t)g * 2 * PF + idx];
-			const uint32_t k = (po == 0) ? c.seed : rice_k_from_sum(sm, n, P.rice_limit);
-			atomicAdd(&pbits[g * 16 + po], rice_bits_estimate(k, n, sm));
-		}
-		__syncthreads();
-		// ---- find_best_partition_order_ (stream_encoder.c:3700-3729): scan max -> min, strict < ----
-		if (tid < ng) {
-			SrCand &c = gc[tid];
-			uint32_t bestb = 0, bestpo = 0;
-			for (int po = (int)c.pmax; po >= (int)c.pmin; po--) {
-				const uint32_t bits = 2 + 4 + pbits[tid * 16 + po];
-				if (bestb == 0 || bits < bestb) {
-					bestb = bits;
-					bestpo = (uint32_t)po;
+			const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
+			const uint32_t span = 2u << pm;
+			if (idx + 1 < span) {
+				const uint32_t r = span - idx;
+				const uint32_t po = ilog2u(r - 1);
+				if (po >= pmn) {
+					const uint32_t part = (2u << po) - r;
+					uint32_t n = bsf >> po;
+					if (part == 0)
+						n -= q.y;
+					const uint32_t k = (po == 0) ? q.z : rice_k_from_sum(sm, n, P.rice_limit);
+					atomicAdd(&pbits[g * 16 + po], rice_bits_estimate(k, n, sm));
 				}
 			}
-			c.best_po = bestpo;
-			c.best_rbits = bestb;
-			c.total_bits = c.hdr_bits + bestb;
 		}
 		__syncthreads();
+		STAMP(7);
+		// ---- find_best_partition_order_ (stream_encoder.c:3700-3729): scan max -> min, strict <;
+		// then the first candidate with the fewest bits wins if it beats what came before ----
 		if (tid < 64) {
-			// the first candidate with the fewest bits wins, if it beats what came before (strict <)
-			uint32_t bits = tid < ng ? gc[tid].total_bits : 0xffffffffu;
-			uint32_t mn = bits;
+			uint32_t total = 0xffffffffu;
+			if (tid < ng) {
+				SrCand &c = gc[tid];
+				uint32_t bestb = 0, bestpo = 0;
+				for (int po = (int)c.pmax; po >= (int)c.pmin; po--) {
+					const uint32_t bits = 2 + 4 + pbits[tid * 16 + po];
+					if (bestb == 0 || bits < bestb) {
+						bestb = bits;
+						bestpo = (uint32_t)po;
+					}
+				}
+				c.best_po = bestpo;
+				c.best_rbits = bestb;
+				total = c.hdr_bits + bestb;
+				c.total_bits = total;
+			}
+			uint32_t mn = total;
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1)
 				mn = umin32(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-			const uint64_t at = __ballot(tid < ng && bits == mn);
+			const uint64_t at = __ballot(tid < ng && total == mn);
 			if (tid == 0) {
 				ctl[2] = (at && mn < best->bits) ? (uint32_t)__ffsll((unsigned long long)at) - 1u : 0xffffffffu;
 				ctl[3] = 0;
@@ -381,19 +545,18 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 			// keep the winner's parameters: its sums are overwritten by the next group
 			const SrCand &c = gc[winner];
 			const uint32_t po = c.best_po;
-			const uint32_t off = (2u << c.pmax) - (2u << po);
 			if (tid < (1u << po)) {
+				const uint64_t sm = sums[(size_t)winner * 2 * PF + (2u << c.pmax) - (2u << po) + tid];
 				uint32_t n = bsf >> po;
 				if (tid == 0)
 					n -= c.order;
-				const uint64_t sm = sums[(size_t)winner * 2 * PF + off + tid];
 				const uint32_t k = (po == 0) ? c.seed : rice_k_from_sum(sm, n, P.rice_limit);
 				best->params[tid] = (uint8_t)k;
 				if (k >= 15)
 					atomicOr(&ctl[3], 1u);  // stream_encoder.c:3752-3757
 			}
 			if (tid < c.order && c.kind == FA_SUB_LPC)
-				best->q[tid] = my_coefs[(size_t)c.slot * P.max_lpc_order + tid];
+				best->q[tid] = cq[winner * MAXORDER + tid];
 			__syncthreads();
 			if (tid == 0) {
 				best->bits = c.total_bits;
@@ -407,6 +570,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 			}
 		}
 		__syncthreads();
+		STAMP(8);
+		first_pass = false;
 	}
 	if (tid == 0 && best->bits == 0xffffffffu) {
 		// stream_encoder.c:3388-3391
@@ -421,40 +586,46 @@ __global__ __launch_bounds__(FA_THREADS) void k_search(FaEncParams P, FaBatch B,
 		for (uint32_t e = tid; e < sizeof(FaPlan) / 4; e += FA_THREADS)
 			dst[e] = src[e];
 	}
+	first_pass = true;
+	STAMP(9);
+#undef STAMP
 }
 
-// LDS for the partition sums: room for every candidate of a subframe in one group when that fits
-static uint32_t search_sum_bytes(const FaEncParams &P)
+// LDS for the finest-partition sums: room for every candidate of a subframe in one group when
+// that fits
+static uint32_t search_sum_bytes(const FaEncParams &P, uint32_t ncmax)
 {
 	uint32_t po = 0;
 	while (po < P.max_po && !((P.blocksize >> po) & 1))
 		po++;
 	const uint32_t per_cand = (2u << po) * 8;
-	uint32_t want = (5 + P.ncand) * per_cand;
-	if (want > SR_MAXGROUP * per_cand)
-		want = SR_MAXGROUP * per_cand;
-	if (want > SR_SUM_BYTES)
-		want = SR_SUM_BYTES;
+	uint32_t want = ncmax * per_cand;
+	if (want > SR_MAXSUM_BYTES)
+		want = SR_MAXSUM_BYTES;
 	if (want < per_cand)
 		want = per_cand;
 	return (want + 15) & ~15u;
 }
 
-static size_t search_lds_bytes(int hist, uint32_t sum_bytes)
-{
-	const size_t stage_words = hist == 4 ? ST_WORDS(4) : hist == 12 ? ST_WORDS(12) : ST_WORDS(32);
-	return sum_bytes + SR_MAXGROUP * 16 * sizeof(uint32_t) + SR_MAXGROUP * sizeof(SrCand) + sizeof(FaPlan) + 16 * sizeof(uint32_t) +
-	       SR_MAXGROUP * FA_MAX_ORDER * sizeof(int32_t) + stage_words * sizeof(int32_t);
-}
-
 void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
-                      const int32_t *coefs, FaPlan *plans, hipStream_t st)
+                      const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st)
 {
 	const dim3 grid(B.nframes * P.nsignals), block(FA_THREADS);
 	const int hist = fa_hist_class(P);
-	const uint32_t sum_bytes = search_sum_bytes(P);
-	const size_t lds = search_lds_bytes(hist, sum_bytes);
-#define SEARCH_LAUNCH(H, N) hipLaunchKernelGGL((k_search<H, N>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes)
+	uint32_t ncmax = 5 + P.ncand;
+	if (ncmax > SR_MAXGROUP)
+		ncmax = SR_MAXGROUP;
+	const uint32_t sum_bytes = search_sum_bytes(P, ncmax);
+	// with one tile per frame the samples are in registers before the sums are first touched, so
+	// the two can share LDS
+	const uint32_t alias = P.blocksize <= FA_TILE ? 1u : 0u;
+	const uint32_t stage_bytes = (hist == 4 ? ST_WORDS(4) : hist == 12 ? ST_WORDS(12) : ST_WORDS(32)) * 4;
+	const uint32_t qstride = hist == 4 ? 4 : hist == 12 ? 12 : 32;
+	const uint32_t ncoef = P.ncand * P.max_lpc_order;
+	const SrLayout L = sr_layout(sum_bytes, stage_bytes, alias, ncmax, qstride, P.ncand < SR_PRE_CANDS ? P.ncand : SR_PRE_CANDS,
+	                             ncoef < SR_PRE_COEFS ? ncoef : SR_PRE_COEFS);
+	const size_t lds = L.total;
+#define SEARCH_LAUNCH(H, N) hipLaunchKernelGGL((k_search<H, N>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps)
 	const bool narrow = fa_narrow_only(P);
 #ifdef EXP_ONLY12
 	SEARCH_LAUNCH(12, true);
