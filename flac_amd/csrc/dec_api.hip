@@ -18,7 +18,7 @@
 
 struct flacamd_decoder {
 	int device;
-	uint32_t channels, bps, max_blocksize, max_frames, number_scale;
+	uint32_t channels, bps, max_blocksize, max_frames, number_scale, lw;
 	uint64_t max_input_bytes;
 	uint32_t max_streams;
 	FaStream *streams;
@@ -105,6 +105,18 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
 	ALLOC(d->ncand, 16);
 	ALLOC(d->tmp, sizeof(int32_t) * groups * 64 * channels * max_blocksize);
+	// frames per wave: few frames are spread thin over many waves (about two per SIMD of the chip)
+	{
+		uint32_t lw = 4;
+		while (lw < 16 && (max_frames + lw - 1) / lw > 2048)
+			lw *= 2;
+		if (const char *env = getenv("FLAC_AMD_DEC_LW")) {
+			const uint32_t v = (uint32_t)atoi(env);
+			if (v >= 1 && v <= 16 && (v & (v - 1)) == 0)
+				lw = v;
+		}
+		d->lw = lw;
+	}
 	ALLOC(d->result, 32);
 #undef ALLOC
 	uint16_t t16[256], pow16[32];
@@ -183,7 +195,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.nstreams = nstreams;
 	P.max_frames = d->max_frames;
 	P.number_scale = d->number_scale;
-	P.pad = 0;
+	P.lw = d->lw;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	const bool prof = d->profiling != 0;

@@ -10,7 +10,7 @@ struct FaDecParams {
 	uint32_t channels, bps, max_blocksize, out_sample_bytes;
 	uint32_t nstreams, max_frames;
 	uint32_t number_scale;   // samples per frame number in fixed-blocksize headers
-	uint32_t pad;
+	uint32_t lw;             // frames per wave in k_dec_frames and per group in the scratch planes (power of two <= 64)
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
 };
@@ -29,7 +29,7 @@ struct FaFrameCand {
 	uint32_t assignment;
 	uint32_t stream;
 	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch, 4 cut off by the end of input
-	uint32_t pad;
+	uint32_t lw;             // frames per wave in k_dec_frames and per group in the scratch planes (power of two <= 64)
 };
 
 void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);

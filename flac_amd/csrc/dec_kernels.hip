@@ -247,34 +247,78 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// bit reader (bitreader.c): MSB-first bits out of big-endian 32-bit words
+// bit reader (bitreader.c): MSB-first bits out of big-endian 32-bit words.
+//
+// A lane keeps the next 32..64 bits of its frame in a register pair and the word after those in a
+// third register.  Words come from a per-lane ring in LDS that the whole wave refills together: 64
+// lanes fetch 64 consecutive words of ONE lane's frame in a single coalesced load, between blocks of
+// samples, long before that lane gets there.  A lane that outruns its ring (a very long unary run)
+// reads global memory itself.
 // ---------------------------------------------------------------------------------------------
+#define DEC_MAXLW 16        // frames per wave at most
+#define RING_CHUNK 64       // words per refill (one per lane of the wave)
+#define RING_WORDS 128      // words per lane in LDS: two chunks
+#define DEC_BLOCK 16        // samples decoded between refill / flush points
+
 struct BitRd {
-	const uint32_t *w;
+	const uint32_t *w;   // the whole input, as words
 	uint64_t nwords;
-	uint64_t pos;   // absolute bit position
-	uint64_t end;   // first bit past the stream
+	uint64_t pos;        // absolute bit position of the window's first bit
+	uint64_t end;        // first bit past the stream
+	uint64_t buf;        // window, left-aligned: bit 63 is the bit at pos
+	uint32_t avail;      // valid bits in buf, kept >= 32
+	uint32_t nxt;        // the word that follows the window (already byte-swapped)
+	uint64_t widx;       // index of the word after nxt
+	uint64_t wbase;      // index of the word chunk 0 starts at
+	uint32_t loaded;     // chunks wbase + [0, loaded * RING_CHUNK) have been in the ring; the last two still are
+	const uint32_t *ring;  // this lane's RING_WORDS words of LDS
 	bool err;
 };
 
-__device__ __forceinline__ uint32_t br_word(const BitRd &r, uint64_t i) { return i < r.nwords ? __builtin_bswap32(r.w[i]) : 0u; }
-
-__device__ __forceinline__ uint32_t br_peek32(const BitRd &r)
+__device__ __forceinline__ uint32_t br_word(const BitRd &r, uint64_t i)
 {
-	const uint64_t i = r.pos >> 5;
-	const uint32_t s = (uint32_t)r.pos & 31;
-	const uint32_t w0 = br_word(r, i);
-	if (s == 0)
-		return w0;
-	return (w0 << s) | (br_word(r, i + 1) >> (32 - s));
+	const uint64_t rel = i - r.wbase;
+	uint32_t v;
+	if (rel < (uint64_t)r.loaded * RING_CHUNK && rel + RING_WORDS >= (uint64_t)r.loaded * RING_CHUNK)
+		v = r.ring[rel & (RING_WORDS - 1)];
+	else
+		v = i < r.nwords ? r.w[i] : 0u;
+	return __builtin_bswap32(v);
+}
+
+__device__ __forceinline__ void br_start(BitRd &r, uint64_t pos)
+{
+	r.pos = pos;
+	r.err = false;
+	const uint64_t i = pos >> 5;
+	const uint32_t s = (uint32_t)pos & 31;
+	const uint64_t two = ((uint64_t)br_word(r, i) << 32) | br_word(r, i + 1);
+	r.buf = two << s;
+	r.avail = 64 - s;
+	r.nxt = br_word(r, i + 2);
+	r.widx = i + 3;
+}
+
+__device__ __forceinline__ void br_consume(BitRd &r, uint32_t n)
+{
+	// n <= 32 <= avail
+	r.buf = n < 64 ? r.buf << n : 0;
+	r.avail -= n;
+	r.pos += n;
+	if (r.avail < 32) {
+		r.buf |= (uint64_t)r.nxt << (32 - r.avail);
+		r.avail += 32;
+		r.nxt = br_word(r, r.widx);
+		r.widx++;
+	}
 }
 
 __device__ __forceinline__ uint32_t br_get(BitRd &r, uint32_t n)
 {
 	if (n == 0)
 		return 0;
-	const uint32_t v = br_peek32(r) >> (32 - n);
-	r.pos += n;
+	const uint32_t v = (uint32_t)(r.buf >> (64 - n));
+	br_consume(r, n);
 	return v;
 }
 
@@ -291,14 +335,14 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 {
 	uint32_t n = 0;
 	for (;;) {
-		const uint32_t v = br_peek32(r);
-		if (v) {
-			const uint32_t z = (uint32_t)__clz((int)v);
-			r.pos += z + 1;
+		const uint32_t hi = (uint32_t)(r.buf >> 32);
+		if (hi) {
+			const uint32_t z = (uint32_t)__clz((int)hi);
+			br_consume(r, z + 1);
 			return n + z;
 		}
 		n += 32;
-		r.pos += 32;
+		br_consume(r, 32);
 		if (r.pos > r.end) {
 			r.err = true;
 			return n;
@@ -310,180 +354,104 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 // k_dec_frames
 // ---------------------------------------------------------------------------------------------
 struct DecLds {
-	int32_t q[FA_MAX_ORDER][DEC_LANES];
+	int32_t q[FA_MAX_ORDER][DEC_MAXLW];          // predictor coefficients per lane
+	int32_t w[FA_MAX_ORDER][DEC_MAXLW];          // warm-up samples per lane
+	uint32_t ring[DEC_MAXLW][RING_WORDS];        // input words per lane
+	int32_t out[DEC_BLOCK * DEC_MAXLW];          // a block of decoded samples, [sample][lane]
 };
 
-// Predictor restore for one channel plane: FLAC__fixed_restore_signal (fixed.c:395) and
-// FLAC__lpc_restore_signal[_wide] (lpc.c:795,1061) as one recurrence; a fixed predictor is the
-// LPC filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 in wrapping 32-bit arithmetic.
-template <int M, bool WIDE, bool MUL24>
-__device__ __forceinline__ void restore_plane(int32_t *plane, const DecLds &L, uint32_t lane, uint32_t bs_w, uint32_t bsf, uint32_t order,
-                                              int shift, bool lane_wide, bool predictive, uint32_t wasted, bool live)
+// The wave-level input pump.  Up to two refills are in flight (one word per thread each); they are
+// put into the rings at the next service point, a block of samples later.
+struct Pump {
+	uint32_t data[2];
+	int lane[2];      // whose ring the word goes to, -1 = slot free
+	uint32_t half[2]; // which half of that ring
+};
+
+// what a lane knows about its current subframe once the subframe header is parsed
+struct SubHdr {
+	uint32_t kind;      // 0 constant, 1 verbatim, 2 fixed, 3 lpc
+	uint32_t order, wasted, sbps;
+	uint32_t po, plen, pesc, psize;
+	int shift;
+	bool lane_wide;
+	int32_t constant;
+};
+
+// Service point (every lane of the wave takes part): land the refills in flight, then start
+// refills for up to two lanes that have moved into the newest chunk of their ring.
+__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint32_t tid, bool live)
 {
-	int32_t q[M > 0 ? M : 1], h[M > 0 ? M : 1];
 #pragma unroll
-	for (int j = 0; j < M; j++) {
-		q[j] = ((uint32_t)j < order && predictive) ? L.q[j][lane] : 0;
-		h[j] = 0;
+	for (int sl = 0; sl < 2; sl++) {
+		if (pm.lane[sl] >= 0) {
+			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = pm.data[sl];
+			if ((int)tid == pm.lane[sl])
+				r.loaded++;
+			pm.lane[sl] = -1;
+		}
 	}
-	for (uint32_t i = 0; i < bs_w; i++) {
-		if (!(live && i < bsf))
-			continue;
-		int32_t v = plane[(size_t)i * DEC_LANES + lane];
-		if (M > 0 && predictive && i >= order) {
-			int32_t pred;
-			if (WIDE) {
-				int64_t sum = 0;
+	// a lane wants chunk `loaded` once its read position is inside chunk `loaded - 1`
+	const bool want = live && !r.err && (r.widx - r.wbase) >= (uint64_t)(r.loaded - 1) * RING_CHUNK &&
+	                  (r.wbase + (uint64_t)r.loaded * RING_CHUNK) < r.nwords;
+	uint64_t m = __ballot(want);
 #pragma unroll
-				for (int j = 0; j < M; j++)
-					sum += (int64_t)q[j] * (int64_t)h[j];
-				pred = lane_wide ? (int32_t)(sum >> shift) : ((int32_t)sum >> shift);
-			} else {
-				int32_t sum = 0;
-#pragma unroll
-				for (int j = 0; j < M; j++)
-					sum += MUL24 ? __mul24(q[j], h[j]) : q[j] * h[j];
-				pred = sum >> shift;
-			}
-			v = (int32_t)((uint32_t)v + (uint32_t)pred);
+	for (int sl = 0; sl < 2; sl++) {
+		if (m) {
+			const int ln = __ffsll((unsigned long long)m) - 1;
+			m &= m - 1;
+			const uint32_t lo = __shfl(r.loaded, ln, 64);
+			const uint64_t wb = ((uint64_t)(uint32_t)__shfl((int)(r.wbase >> 32), ln, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.wbase, ln, 64);
+			const uint64_t at = wb + (uint64_t)lo * RING_CHUNK + tid;
+			pm.data[sl] = at < r.nwords ? r.w[at] : 0u;
+			pm.lane[sl] = ln;
+			pm.half[sl] = lo & 1;
 		}
-		if (M > 0) {
-#pragma unroll
-			for (int j = M - 1; j > 0; j--)
-				h[j] = h[j - 1];
-			h[0] = v;
-		}
-		// wasted bits are restored after prediction (stream_decoder.c:2511-2515)
-		plane[(size_t)i * DEC_LANES + lane] = (int32_t)((uint32_t)v << wasted);
 	}
 }
 
-__global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
-                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp)
+// The samples of one subframe for every lane of the wave: verbatim words, or Rice-coded residuals
+// (stream_decoder.c:2692,2715) turned into samples on the spot by the predictor recurrence
+// (FLAC__fixed_restore_signal, fixed.c:395; FLAC__lpc_restore_signal[_wide], lpc.c:795,1061; a
+// fixed predictor is the LPC filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 in wrapping
+// 32-bit arithmetic).  M bounds the predictor orders present in the wave.  Samples, shifted back
+// up by the wasted bits (stream_decoder.c:2511-2515), are collected a block at a time in LDS and
+// written to plane[sample * LW + lane] by all threads together.
+template <int M, bool WIDE, bool MUL24>
+__device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, DecLds &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
+                                               uint32_t bsf, bool live)
 {
-	__shared__ DecLds L;
-	const uint32_t lane = threadIdx.x;
-	const uint32_t ncand = ncand_ptr[0];
-	if (blockIdx.x * DEC_LANES >= ncand)
-		return;
-	const uint32_t j = blockIdx.x * DEC_LANES + lane;
-	const bool live = j < ncand;
-	FaFrameCand cd;
-	if (live)
-		cd = cands[j];
-	else {
-		cd.pos = 0; cd.sample = 0; cd.hdr_bytes = 0; cd.blocksize = 0; cd.assignment = 0; cd.stream = 0; cd.status = 0; cd.end_byte = 0;
-	}
-	BitRd r;
-	r.w = flac_words;
-	r.nwords = (P.flac_bytes + 3) / 4;
-	r.pos = (cd.pos + cd.hdr_bytes) * 8;
-	r.end = live ? (streams[cd.stream].byte_offset + streams[cd.stream].byte_length) * 8 : 0;
-	r.err = false;
-	const uint32_t bsf = cd.blocksize;
-	uint32_t bs_w = bsf;
+	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
+	const bool predictive = h.kind >= 2;
+	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		const uint32_t t = __shfl_xor(bs_w, o, 64);
-		bs_w = t > bs_w ? t : bs_w;
+	for (int j = 0; j < M; j++) {
+		q[j] = ((uint32_t)j < h.order && predictive && tid < DEC_MAXLW) ? L.q[j][lane] : 0;
+		hist[j] = 0;
 	}
-	int32_t *frame_tmp = tmp + (size_t)blockIdx.x * P.channels * P.max_blocksize * DEC_LANES;
-
-	for (uint32_t c = 0; c < P.channels; c++) {
-		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * DEC_LANES;
-		// ---- subframe header (stream_decoder.c:2450-2518) ----
-		uint32_t sbps = P.bps;
-		if ((cd.assignment == 1 && c == 1) || (cd.assignment == 2 && c == 0) || (cd.assignment == 3 && c == 1))
-			sbps++;
-		uint32_t kind = 0;  // 0 constant, 1 verbatim, 2 fixed, 3 lpc
-		uint32_t order = 0, wasted = 0, po = 0, plen = 4, pesc = 15, psize = 0;
-		int shift = 0;
-		bool lane_wide = false;
-		int32_t constant = 0;
-		const bool ok_in = live && !r.err;
-		if (ok_in) {
-			uint32_t x = br_get(r, 8);
-			const uint32_t has_wasted = x & 1;
-			x &= 0xfe;
-			if (has_wasted) {
-				wasted = br_unary(r) + 1;
-				if (wasted >= sbps)
-					r.err = true;
-				else
-					sbps -= wasted;
-			}
-			if (x & 0x80) r.err = true;
-			else if (x == 0) kind = 0;
-			else if (x == 2) kind = 1;
-			else if (x < 16) r.err = true;
-			else if (x <= 24) {
-				kind = 2;
-				order = (x >> 1) & 7;
-				if (order > 4) r.err = true;
-			} else if (x < 64) r.err = true;
-			else {
-				kind = 3;
-				order = ((x >> 1) & 31) + 1;
-			}
-			if (order > bsf)
-				r.err = true;
-		}
-		if (ok_in && !r.err) {
-			if (kind == 0)
-				constant = br_get_signed(r, sbps);
-			if (kind >= 2) {
-				for (uint32_t i = 0; i < order; i++)
-					plane[(size_t)i * DEC_LANES + lane] = br_get_signed(r, sbps);
-				if (kind == 3) {
-					uint32_t prec = br_get(r, 4);
-					if (prec == 15)
-						r.err = true;  // stream_decoder.c:2622
-					prec++;
-					shift = br_get_signed(r, 5);
-					if (shift < 0)
-						shift = 0;  // the reference's shift by a negative count is undefined; it never writes one
-					for (uint32_t i = 0; i < order; i++)
-						L.q[i][lane] = br_get_signed(r, prec);
-					lane_wide = !(sbps + prec + d_ilog2(order) <= 32);  // stream_decoder.c:2676
-				} else {
-					for (uint32_t i = 0; i < order; i++)
-						L.q[i][lane] = c_fixed_q[order][i];
-				}
-				const uint32_t method = br_get(r, 2);
-				if (method > 1)
-					r.err = true;
-				if (method == 1) {
-					plen = 5;
-					pesc = 31;
-				}
-				po = br_get(r, 4);
-				// stream_decoder.c:2721-2739
-				psize = po > 0 ? bsf >> po : bsf - order;
-				if (po > 0 && (psize < order || (psize << po) != bsf))
-					r.err = true;
-			}
-		}
-		// ---- samples: verbatim words or Rice-coded residual (stream_decoder.c:2692,2715) ----
-		uint32_t next_part = order;   // sample index where the next partition parameter is read
-		uint32_t k = 0, raw_bits = 0;
-		bool escape = false;
-		for (uint32_t i = 0; i < bs_w; i++) {
+	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
+	uint32_t k = 0, raw_bits = 0;
+	bool escape = false;
+	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
+		pump_service(pm, r, L, tid, live);
+		const uint32_t iend = i0 + DEC_BLOCK < bs_w ? i0 + DEC_BLOCK : bs_w;
+		for (uint32_t i = i0; i < iend; i++) {
 			if (!(live && !r.err && i < bsf))
 				continue;
 			int32_t v;
-			if (kind == 0)
-				v = constant;
-			else if (kind == 1)
-				v = br_get_signed(r, sbps);
+			if (h.kind == 0)
+				v = h.constant;
+			else if (h.kind == 1)
+				v = br_get_signed(r, h.sbps);
+			else if (i < h.order)
+				v = L.w[i][lane];
 			else {
-				if (i < order)
-					continue;  // warm-up already stored
 				if (i == next_part) {
-					k = br_get(r, plen);
-					escape = k >= pesc;
+					k = br_get(r, h.plen);
+					escape = k >= h.pesc;
 					if (escape)
 						raw_bits = br_get(r, 5);
-					next_part = (po > 0) ? ((i / psize) + 1) * psize : bsf;
+					next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
 				}
 				if (escape)
 					v = br_get_signed(r, raw_bits);
@@ -496,33 +464,194 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 				}
 				if (r.pos > r.end)
 					r.err = true;
+				if (M > 0) {
+					int32_t pred;
+					if (WIDE) {
+						int64_t sum = 0;
+#pragma unroll
+						for (int j = 0; j < M; j++)
+							sum += (int64_t)q[j] * (int64_t)hist[j];
+						pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
+					} else {
+						int32_t sum = 0;
+#pragma unroll
+						for (int j = 0; j < M; j++)
+							sum += MUL24 ? __mul24(q[j], hist[j]) : q[j] * hist[j];
+						pred = sum >> h.shift;
+					}
+					v = (int32_t)((uint32_t)v + (uint32_t)pred);
+				}
 			}
-			plane[(size_t)i * DEC_LANES + lane] = v;
+			if (M > 0 && predictive) {
+#pragma unroll
+				for (int j = M - 1; j > 0; j--)
+					hist[j] = hist[j - 1];
+				hist[0] = v;
+			}
+			L.out[(i - i0) * LW + lane] = (int32_t)((uint32_t)v << h.wasted);
 		}
-		// ---- predictor restore, dispatched on what the wave as a whole needs ----
-		const bool predictive = kind >= 2 && live && !r.err;
-		uint32_t need = predictive ? order : 0;
+		// the block goes out with all 64 threads along memory order
+		for (uint32_t e = tid; e < (iend - i0) * LW; e += DEC_LANES)
+			plane[(size_t)i0 * LW + e] = L.out[e];
+	}
+}
+
+// One lane per frame; a wave carries LW <= 16 frames in its first lanes, the other lanes only help
+// moving data.  A wave's pace is set by its longest dependent chain, not by how many of its lanes
+// decode, so a batch is spread over as many waves as the chip can run at once.
+__global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
+                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW)
+{
+	__shared__ DecLds L;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t ncand = ncand_ptr[0];
+	if (blockIdx.x * LW >= ncand)
+		return;
+	const uint32_t j = blockIdx.x * LW + tid;
+	const bool live = tid < LW && j < ncand;
+	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
+	FaFrameCand cd;
+	if (live)
+		cd = cands[j];
+	else {
+		cd.pos = 0; cd.sample = 0; cd.hdr_bytes = 0; cd.blocksize = 0; cd.assignment = 0; cd.stream = 0; cd.status = 0; cd.end_byte = 0;
+	}
+	BitRd r;
+	r.w = flac_words;
+	r.nwords = (P.flac_bytes + 3) / 4;
+	r.end = live ? (streams[cd.stream].byte_offset + streams[cd.stream].byte_length) * 8 : 0;
+	r.wbase = cd.pos >> 2;
+	r.loaded = 0;
+	r.ring = L.ring[lane];
+	// the first two chunks of every frame, all requested before the first is waited for
+	{
+		uint32_t first[2 * DEC_MAXLW];
+#pragma unroll
+		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
+			const uint64_t wb = ((uint64_t)(uint32_t)__shfl((int)(r.wbase >> 32), (int)ln, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.wbase, (int)ln, 64);
+#pragma unroll
+			for (uint32_t c = 0; c < 2; c++) {
+				const uint64_t at = wb + c * RING_CHUNK + tid;
+				first[2 * ln + c] = (ln < LW && at < r.nwords) ? flac_words[at] : 0u;
+			}
+		}
+#pragma unroll
+		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
+			L.ring[ln][tid] = first[2 * ln];
+			L.ring[ln][RING_CHUNK + tid] = first[2 * ln + 1];
+		}
+		r.loaded = 2;
+	}
+	Pump pm;
+	pm.lane[0] = pm.lane[1] = -1;
+	pm.data[0] = pm.data[1] = 0;
+	pm.half[0] = pm.half[1] = 0;
+	br_start(r, (cd.pos + cd.hdr_bytes) * 8);
+	const uint32_t bsf = cd.blocksize;
+	uint32_t bs_w = bsf;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t t = __shfl_xor(bs_w, o, 64);
+		bs_w = t > bs_w ? t : bs_w;
+	}
+	int32_t *frame_tmp = tmp + (size_t)blockIdx.x * P.channels * P.max_blocksize * LW;
+
+	for (uint32_t c = 0; c < P.channels; c++) {
+		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
+		pump_service(pm, r, L, tid, live);
+		// ---- subframe header (stream_decoder.c:2450-2518) ----
+		SubHdr h;
+		h.kind = 0; h.order = 0; h.wasted = 0; h.po = 0; h.plen = 4; h.pesc = 15; h.psize = 0; h.shift = 0; h.lane_wide = false; h.constant = 0;
+		h.sbps = P.bps;
+		if ((cd.assignment == 1 && c == 1) || (cd.assignment == 2 && c == 0) || (cd.assignment == 3 && c == 1))
+			h.sbps++;
+		const bool ok_in = live && !r.err;
+		if (ok_in) {
+			uint32_t x = br_get(r, 8);
+			const uint32_t has_wasted = x & 1;
+			x &= 0xfe;
+			if (has_wasted) {
+				h.wasted = br_unary(r) + 1;
+				if (h.wasted >= h.sbps)
+					r.err = true;
+				else
+					h.sbps -= h.wasted;
+			}
+			if (x & 0x80) r.err = true;
+			else if (x == 0) h.kind = 0;
+			else if (x == 2) h.kind = 1;
+			else if (x < 16) r.err = true;
+			else if (x <= 24) {
+				h.kind = 2;
+				h.order = (x >> 1) & 7;
+				if (h.order > 4) r.err = true;
+			} else if (x < 64) r.err = true;
+			else {
+				h.kind = 3;
+				h.order = ((x >> 1) & 31) + 1;
+			}
+			if (h.order > bsf)
+				r.err = true;
+		}
+		if (ok_in && !r.err) {
+			if (h.kind == 0)
+				h.constant = br_get_signed(r, h.sbps);
+			if (h.kind >= 2) {
+				for (uint32_t i = 0; i < h.order; i++)
+					L.w[i][lane] = br_get_signed(r, h.sbps);
+				if (h.kind == 3) {
+					uint32_t prec = br_get(r, 4);
+					if (prec == 15)
+						r.err = true;  // stream_decoder.c:2622
+					prec++;
+					h.shift = br_get_signed(r, 5);
+					if (h.shift < 0)
+						h.shift = 0;  // the reference's shift by a negative count is undefined; it never writes one
+					for (uint32_t i = 0; i < h.order; i++)
+						L.q[i][lane] = br_get_signed(r, prec);
+					h.lane_wide = !(h.sbps + prec + d_ilog2(h.order) <= 32);  // stream_decoder.c:2676
+				} else {
+					for (uint32_t i = 0; i < h.order; i++)
+						L.q[i][lane] = c_fixed_q[h.order][i];
+				}
+				const uint32_t method = br_get(r, 2);
+				if (method > 1)
+					r.err = true;
+				if (method == 1) {
+					h.plen = 5;
+					h.pesc = 31;
+				}
+				h.po = br_get(r, 4);
+				// stream_decoder.c:2721-2739
+				h.psize = h.po > 0 ? bsf >> h.po : bsf - h.order;
+				if (h.po > 0 && (h.psize < h.order || (h.psize << h.po) != bsf))
+					r.err = true;
+			}
+		}
+		// ---- samples, dispatched on what the wave as a whole needs ----
+		const bool predictive = h.kind >= 2 && live && !r.err;
+		uint32_t need = predictive ? h.order : 0;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
 			const uint32_t t = __shfl_xor(need, o, 64);
 			need = t > need ? t : need;
 		}
-		const bool any_wide = __any(predictive && lane_wide);
-		const bool all24 = __all(!predictive || sbps <= 24);
+		const bool any_wide = __any(predictive && h.lane_wide);
+		const bool all24 = __all(!predictive || h.sbps <= 24);
 		const bool run = live && !r.err;
-#define RESTORE(M) \
+#define DECODE(M) \
 	do { \
-		if (any_wide) restore_plane<M, true, false>(plane, L, lane, bs_w, bsf, order, shift, lane_wide, predictive, wasted, run); \
-		else if (all24) restore_plane<M, false, true>(plane, L, lane, bs_w, bsf, order, shift, lane_wide, predictive, wasted, run); \
-		else restore_plane<M, false, false>(plane, L, lane, bs_w, bsf, order, shift, lane_wide, predictive, wasted, run); \
+		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
+		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
+		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
 	} while (0)
-		if (need == 0) RESTORE(0);
-		else if (need <= 4) RESTORE(4);
-		else if (need <= 8) RESTORE(8);
-		else if (need <= 12) RESTORE(12);
-		else if (need <= 16) RESTORE(16);
-		else RESTORE(32);
-#undef RESTORE
+		if (need == 0) DECODE(0);
+		else if (need <= 4) DECODE(4);
+		else if (need <= 8) DECODE(8);
+		else if (need <= 12) DECODE(12);
+		else if (need <= 16) DECODE(16);
+		else DECODE(32);
+#undef DECODE
 	}
 	if (live) {
 		// read_zero_padding_ (stream_decoder.c:2773): the pad bits must be zero
@@ -606,39 +735,49 @@ __global__ __launch_bounds__(256) void k_dec_crc(const uint8_t *d, FaFrameCand *
 // ---------------------------------------------------------------------------------------------
 #define OUT_LDS_BYTES 32768
 
+// Scratch planes [group of LW frames][channel][sample][LW] -> interleaved PCM.  Phase 1 reads the
+// planes with threads along (sample, frame), which is their memory order, undoes the stereo
+// decorrelation and drops the values into LDS frame by frame; phase 2 writes each frame's run of
+// the tile with lanes along the run.
 __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand_ptr,
-                                                    const int32_t *tmp, void *out, uint32_t tile_samples)
+                                                    const int32_t *tmp, void *out, uint32_t tile_samples, uint32_t LW, uint32_t lw_log)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	__shared__ FaFrameCand sc[DEC_LANES];
 	const uint32_t ncand = ncand_ptr[0];
 	const uint32_t g = blockIdx.x;
-	if (g * DEC_LANES >= ncand)
+	if (g * LW >= ncand)
 		return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t i0 = blockIdx.y * tile_samples;
 	const uint32_t ch = P.channels, sb = P.out_sample_bytes;
-	const uint32_t j = g * DEC_LANES + lane;
-	const bool live = j < ncand;
-	FaFrameCand cd;
-	cd.blocksize = 0;
-	cd.status = 0;
-	cd.assignment = 0;
-	if (live)
-		cd = cands[j];
-	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * DEC_LANES;
+	if (tid < LW) {
+		FaFrameCand cd;
+		cd.blocksize = 0;
+		cd.status = 0;
+		cd.assignment = 0;
+		cd.sample = 0;
+		cd.stream = 0;
+		if (g * LW + tid < ncand)
+			cd = cands[g * LW + tid];
+		sc[tid] = cd;
+	}
+	__syncthreads();
+	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * LW;
 	const uint32_t row = tile_samples * ch;  // elements per frame in the tile
-	// phase 1: lane = frame; each wave takes every 4th sample of the tile
-	for (uint32_t ii = wv; ii < tile_samples; ii += 4) {
+	for (uint32_t idx = tid; idx < tile_samples * LW; idx += 256) {
+		const uint32_t fl = idx & (LW - 1), ii = idx >> lw_log;
 		const uint32_t i = i0 + ii;
-		if (!(live && cd.status == 1 && i < cd.blocksize))
+		if (!(sc[fl].status == 1 && i < sc[fl].blocksize))
 			continue;
-		if (ch == 2 && cd.assignment != 0) {
-			int32_t a = frame_tmp[(size_t)i * DEC_LANES + lane];
-			int32_t b = frame_tmp[((size_t)P.max_blocksize + i) * DEC_LANES + lane];
+		const uint32_t assignment = sc[fl].assignment;
+		if (ch == 2 && assignment != 0) {
+			int32_t a = frame_tmp[(size_t)i * LW + fl];
+			int32_t b = frame_tmp[((size_t)P.max_blocksize + i) * LW + fl];
 			// stream_decoder.c:2067-2102
-			if (cd.assignment == 1)
+			if (assignment == 1)
 				b = a - b;
-			else if (cd.assignment == 2)
+			else if (assignment == 2)
 				a = a + b;
 			else {
 				int32_t mid = (int32_t)((uint32_t)a << 1);
@@ -647,29 +786,25 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 				b = (mid - b) >> 1;
 			}
 			if (sb == 2) {
-				((int16_t *)lds)[lane * row + ii * 2] = (int16_t)a;
-				((int16_t *)lds)[lane * row + ii * 2 + 1] = (int16_t)b;
+				((int16_t *)lds)[fl * row + ii * 2] = (int16_t)a;
+				((int16_t *)lds)[fl * row + ii * 2 + 1] = (int16_t)b;
 			} else {
-				((int32_t *)lds)[lane * row + ii * 2] = a;
-				((int32_t *)lds)[lane * row + ii * 2 + 1] = b;
+				((int32_t *)lds)[fl * row + ii * 2] = a;
+				((int32_t *)lds)[fl * row + ii * 2 + 1] = b;
 			}
 		} else {
 			for (uint32_t c = 0; c < ch; c++) {
-				const int32_t v = frame_tmp[((size_t)c * P.max_blocksize + i) * DEC_LANES + lane];
+				const int32_t v = frame_tmp[((size_t)c * P.max_blocksize + i) * LW + fl];
 				if (sb == 2)
-					((int16_t *)lds)[lane * row + ii * ch + c] = (int16_t)v;
+					((int16_t *)lds)[fl * row + ii * ch + c] = (int16_t)v;
 				else
-					((int32_t *)lds)[lane * row + ii * ch + c] = v;
+					((int32_t *)lds)[fl * row + ii * ch + c] = v;
 			}
 		}
 	}
 	__syncthreads();
-	// phase 2: each wave writes whole frames' runs, lanes along the run
-	for (uint32_t fl = wv; fl < DEC_LANES; fl += 4) {
-		const uint32_t jf = g * DEC_LANES + fl;
-		if (jf >= ncand)
-			break;
-		const FaFrameCand cf = cands[jf];
+	for (uint32_t fl = wv; fl < LW; fl += 4) {
+		const FaFrameCand &cf = sc[fl];
 		if (cf.status != 1 || i0 >= cf.blocksize)
 			continue;
 		const FaStream st = streams[cf.stream];
@@ -734,8 +869,8 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
                           int32_t *tmp, hipStream_t st)
 {
-	const uint32_t groups = (P.max_frames + DEC_LANES - 1) / DEC_LANES;
-	hipLaunchKernelGGL(k_dec_frames, dim3(groups), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp);
+	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
+	hipLaunchKernelGGL(k_dec_frames, dim3(groups), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw);
 }
 
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)
@@ -749,12 +884,17 @@ void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *c
 void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
                           void *out, unsigned long long *result, hipStream_t st)
 {
-	uint32_t tile = OUT_LDS_BYTES / (DEC_LANES * P.channels * P.out_sample_bytes);
-	if (tile > 64)
-		tile = 64;
-	const uint32_t groups = (P.max_frames + DEC_LANES - 1) / DEC_LANES;
+	uint32_t tile = OUT_LDS_BYTES / (P.lw * P.channels * P.out_sample_bytes);
+	if (tile > 512)
+		tile = 512;
+	if (tile > P.max_blocksize)
+		tile = P.max_blocksize;
+	uint32_t lw_log = 0;
+	while ((1u << lw_log) < P.lw)
+		lw_log++;
+	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
 	const uint32_t tiles = (P.max_blocksize + tile - 1) / tile;
-	const size_t lds = (size_t)DEC_LANES * tile * P.channels * P.out_sample_bytes;
-	hipLaunchKernelGGL(k_dec_output, dim3(groups, tiles), dim3(256), lds, st, P, streams, cands, ncand, tmp, out, tile);
+	const size_t lds = (size_t)P.lw * tile * P.channels * P.out_sample_bytes;
+	hipLaunchKernelGGL(k_dec_output, dim3(groups, tiles), dim3(256), lds, st, P, streams, cands, ncand, tmp, out, tile, P.lw, lw_log);
 	hipLaunchKernelGGL(k_dec_summary, dim3(64), dim3(256), 0, st, cands, ncand, result);
 }
