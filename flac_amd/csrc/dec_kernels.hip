@@ -261,64 +261,71 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 #define DEC_BLOCK 16        // samples decoded between refill / flush points
 
 struct BitRd {
-	const uint32_t *w;   // the whole input, as words
-	uint64_t nwords;
-	uint64_t pos;        // absolute bit position of the window's first bit
-	uint64_t end;        // first bit past the stream
-	uint64_t buf;        // window, left-aligned: bit 63 is the bit at pos
-	uint32_t avail;      // valid bits in buf, kept >= 32
+	const uint32_t *wg;  // the frame's first word in global memory (word index wbase of the input)
+	uint64_t wbase;      // index of that word in the input
+	uint64_t buf;        // window, left-aligned: bit 63 is the bit at bpos
+	uint32_t avail;      // valid bits in buf; 33..64 after br_refill
 	uint32_t nxt;        // the word that follows the window (already byte-swapped)
-	uint64_t widx;       // index of the word after nxt
-	uint64_t wbase;      // index of the word chunk 0 starts at
-	uint32_t loaded;     // chunks wbase + [0, loaded * RING_CHUNK) have been in the ring; the last two still are
+	uint32_t wrel;       // index, relative to wbase, of the word after nxt
+	uint32_t nrel;       // words from wbase to the end of the input (saturated)
+	uint32_t limit;      // words [0, limit) have been in the ring; the last RING_WORDS of them still are
+	uint32_t bpos;       // bits consumed, counted from the start of word wbase
+	uint32_t bend;       // first bit past the stream on the same scale (saturated)
 	const uint32_t *ring;  // this lane's RING_WORDS words of LDS
 	bool err;
 };
 
-__device__ __forceinline__ uint32_t br_word(const BitRd &r, uint64_t i)
+// The refill protocol keeps limit - RING_WORDS <= wrel, so one compare tells whether the ring has
+// the word; a lane that has outrun its ring reads global memory itself.
+__device__ __forceinline__ uint32_t br_fetch(BitRd &r)
 {
-	const uint64_t rel = i - r.wbase;
 	uint32_t v;
-	if (rel < (uint64_t)r.loaded * RING_CHUNK && rel + RING_WORDS >= (uint64_t)r.loaded * RING_CHUNK)
-		v = r.ring[rel & (RING_WORDS - 1)];
+	if (r.wrel < r.limit)
+		v = r.ring[r.wrel & (RING_WORDS - 1)];
 	else
-		v = i < r.nwords ? r.w[i] : 0u;
+		v = r.wrel < r.nrel ? r.wg[r.wrel] : 0u;
+	r.wrel++;
 	return __builtin_bswap32(v);
 }
 
-__device__ __forceinline__ void br_start(BitRd &r, uint64_t pos)
+// start reading at bit sbit (< 32 * RING_CHUNK - 96) of the frame's first chunk
+__device__ __forceinline__ void br_start(BitRd &r, uint32_t sbit)
 {
-	r.pos = pos;
 	r.err = false;
-	const uint64_t i = pos >> 5;
-	const uint32_t s = (uint32_t)pos & 31;
-	const uint64_t two = ((uint64_t)br_word(r, i) << 32) | br_word(r, i + 1);
+	r.bpos = sbit;
+	const uint32_t i = sbit >> 5, s = sbit & 31;
+	const uint64_t two = ((uint64_t)__builtin_bswap32(r.ring[i]) << 32) | __builtin_bswap32(r.ring[i + 1]);
 	r.buf = two << s;
 	r.avail = 64 - s;
-	r.nxt = br_word(r, i + 2);
-	r.widx = i + 3;
+	r.nxt = __builtin_bswap32(r.ring[i + 2]);
+	r.wrel = i + 3;
 }
 
-__device__ __forceinline__ void br_consume(BitRd &r, uint32_t n)
+// afterwards the window holds at least 33 bits
+__device__ __forceinline__ void br_refill(BitRd &r)
 {
-	// n <= 32 <= avail
-	r.buf = n < 64 ? r.buf << n : 0;
-	r.avail -= n;
-	r.pos += n;
-	if (r.avail < 32) {
+	if (r.avail <= 32) {
 		r.buf |= (uint64_t)r.nxt << (32 - r.avail);
 		r.avail += 32;
-		r.nxt = br_word(r, r.widx);
-		r.widx++;
+		r.nxt = br_fetch(r);
 	}
+}
+
+// n <= 32, after br_refill
+__device__ __forceinline__ void br_drop(BitRd &r, uint32_t n)
+{
+	r.buf <<= n;
+	r.avail -= n;
+	r.bpos += n;
 }
 
 __device__ __forceinline__ uint32_t br_get(BitRd &r, uint32_t n)
 {
 	if (n == 0)
 		return 0;
+	br_refill(r);
 	const uint32_t v = (uint32_t)(r.buf >> (64 - n));
-	br_consume(r, n);
+	br_drop(r, n);
 	return v;
 }
 
@@ -335,15 +342,16 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 {
 	uint32_t n = 0;
 	for (;;) {
+		br_refill(r);
 		const uint32_t hi = (uint32_t)(r.buf >> 32);
 		if (hi) {
 			const uint32_t z = (uint32_t)__clz((int)hi);
-			br_consume(r, z + 1);
+			br_drop(r, z + 1);
 			return n + z;
 		}
 		n += 32;
-		br_consume(r, 32);
-		if (r.pos > r.end) {
+		br_drop(r, 32);
+		if (r.bpos > r.bend) {
 			r.err = true;
 			return n;
 		}
@@ -357,7 +365,7 @@ struct DecLds {
 	int32_t q[FA_MAX_ORDER][DEC_MAXLW];          // predictor coefficients per lane
 	int32_t w[FA_MAX_ORDER][DEC_MAXLW];          // warm-up samples per lane
 	uint32_t ring[DEC_MAXLW][RING_WORDS];        // input words per lane
-	int32_t out[DEC_BLOCK * DEC_MAXLW];          // a block of decoded samples, [sample][lane]
+	int32_t out[2 * DEC_BLOCK * DEC_MAXLW];      // a block of decoded samples, [sample][lane]; second half: spare
 };
 
 // The wave-level input pump.  Up to two refills are in flight (one word per thread each); they are
@@ -378,34 +386,35 @@ struct SubHdr {
 	int32_t constant;
 };
 
+__device__ __forceinline__ uint32_t wave_value(uint32_t v, int lane_id) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_id); }
+
 // Service point (every lane of the wave takes part): land the refills in flight, then start
 // refills for up to two lanes that have moved into the newest chunk of their ring.
-__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint32_t tid, bool live)
+__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint32_t tid, bool live, uint64_t nwords)
 {
 #pragma unroll
 	for (int sl = 0; sl < 2; sl++) {
 		if (pm.lane[sl] >= 0) {
 			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = pm.data[sl];
 			if ((int)tid == pm.lane[sl])
-				r.loaded++;
+				r.limit += RING_CHUNK;
 			pm.lane[sl] = -1;
 		}
 	}
-	// a lane wants chunk `loaded` once its read position is inside chunk `loaded - 1`
-	const bool want = live && !r.err && (r.widx - r.wbase) >= (uint64_t)(r.loaded - 1) * RING_CHUNK &&
-	                  (r.wbase + (uint64_t)r.loaded * RING_CHUNK) < r.nwords;
+	// a lane wants the next chunk once its read position is inside the newest one
+	const bool want = live && !r.err && r.wrel + RING_CHUNK >= r.limit && r.limit < r.nrel;
 	uint64_t m = __ballot(want);
 #pragma unroll
 	for (int sl = 0; sl < 2; sl++) {
 		if (m) {
 			const int ln = __ffsll((unsigned long long)m) - 1;
 			m &= m - 1;
-			const uint32_t lo = __shfl(r.loaded, ln, 64);
-			const uint64_t wb = ((uint64_t)(uint32_t)__shfl((int)(r.wbase >> 32), ln, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.wbase, ln, 64);
-			const uint64_t at = wb + (uint64_t)lo * RING_CHUNK + tid;
-			pm.data[sl] = at < r.nwords ? r.w[at] : 0u;
+			const uint32_t lim = wave_value(r.limit, ln);
+			const uint64_t wb = ((uint64_t)wave_value((uint32_t)(r.wbase >> 32), ln) << 32) | wave_value((uint32_t)r.wbase, ln);
+			const uint64_t at = wb + lim + tid;
+			pm.data[sl] = at < nwords ? (r.wg - r.wbase)[at] : 0u;
 			pm.lane[sl] = ln;
-			pm.half[sl] = lo & 1;
+			pm.half[sl] = (lim / RING_CHUNK) & 1;
 		}
 	}
 }
@@ -414,12 +423,22 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 // (stream_decoder.c:2692,2715) turned into samples on the spot by the predictor recurrence
 // (FLAC__fixed_restore_signal, fixed.c:395; FLAC__lpc_restore_signal[_wide], lpc.c:795,1061; a
 // fixed predictor is the LPC filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 in wrapping
-// 32-bit arithmetic).  M bounds the predictor orders present in the wave.  Samples, shifted back
-// up by the wasted bits (stream_decoder.c:2511-2515), are collected a block at a time in LDS and
-// written to plane[sample * LW + lane] by all threads together.
+// 32-bit arithmetic).  M bounds the predictor orders present in the wave.
+//
+// The common case runs without control flow: every lane cuts a Rice symbol out of its 33..64-bit
+// window (one count of leading zeros, two shifts), predicts, shifts its history and tops the window
+// up from the ring word requested at the start of the sample.  Lanes for which that is not the right
+// thing at this sample (warm-up and verbatim samples, a partition boundary, an escaped partition,
+// a symbol longer than the window, a ring that has fallen behind) throw the result away and take
+// the one divergent region, which uses the general bit reader.  Because the prediction and the
+// history shift run for all lanes on every sample, the history is renamed across the unrolled
+// samples rather than moved.
+//
+// Samples, shifted back up by the wasted bits (stream_decoder.c:2511-2515), are collected a block
+// at a time in LDS and written to plane[sample * LW + lane] by all threads together.
 template <int M, bool WIDE, bool MUL24>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, DecLds &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
-                                               uint32_t bsf, bool live)
+                                               uint32_t bsf, bool live, uint64_t nwords)
 {
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
 	const bool predictive = h.kind >= 2;
@@ -432,66 +451,106 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
 	uint32_t k = 0, raw_bits = 0;
 	bool escape = false;
+	// samples [seg_lo, seg_lo + seg_len) are plain Rice symbols with parameter k
+	uint32_t seg_lo = 0, seg_len = 0;
+	// samples below work_end need parsing; a constant subframe needs none
+	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
+	br_refill(r);
+	// lanes that carry no frame write their block samples to a spare area
+	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * DEC_MAXLW];
 	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
-		pump_service(pm, r, L, tid, live);
-		const uint32_t iend = i0 + DEC_BLOCK < bs_w ? i0 + DEC_BLOCK : bs_w;
-		for (uint32_t i = i0; i < iend; i++) {
-			if (!(live && !r.err && i < bsf))
-				continue;
-			int32_t v;
-			if (h.kind == 0)
-				v = h.constant;
-			else if (h.kind == 1)
-				v = br_get_signed(r, h.sbps);
-			else if (i < h.order)
-				v = L.w[i][lane];
-			else {
-				if (i == next_part) {
-					k = br_get(r, h.plen);
-					escape = k >= h.pesc;
-					if (escape)
-						raw_bits = br_get(r, 5);
-					next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
-				}
-				if (escape)
-					v = br_get_signed(r, raw_bits);
-				else {
-					// FLAC__bitreader_read_rice_signed_block (bitreader.c:775)
-					const uint32_t msbs = br_unary(r);
-					const uint32_t lsbs = br_get(r, k);
-					const uint32_t u = (msbs << k) | lsbs;
-					v = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
-				}
-				if (r.pos > r.end)
-					r.err = true;
-				if (M > 0) {
-					int32_t pred;
-					if (WIDE) {
-						int64_t sum = 0;
-#pragma unroll
-						for (int j = 0; j < M; j++)
-							sum += (int64_t)q[j] * (int64_t)hist[j];
-						pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
-					} else {
-						int32_t sum = 0;
-#pragma unroll
-						for (int j = 0; j < M; j++)
-							sum += MUL24 ? __mul24(q[j], hist[j]) : q[j] * hist[j];
-						pred = sum >> h.shift;
+		pump_service(pm, r, L, tid, live, nwords);
+		if (r.bpos > r.bend) {
+			r.err = true;
+			work_end = 0;
+			seg_len = 0;
+		}
+#pragma unroll 4
+		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+			const uint32_t i = i0 + s;
+			// the word a refill at the end of this sample would take
+			const uint32_t ring_word = r.ring[r.wrel & (RING_WORDS - 1)];
+			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the window
+			const uint32_t hi = (uint32_t)(r.buf >> 32);
+			const uint32_t z = (uint32_t)__clz((int)hi);  // 32 when hi is 0
+			const uint32_t total = z + 1 + k;
+			const bool fast = (i - seg_lo) < seg_len && hi != 0 && total <= r.avail && r.wrel < r.limit;
+			const uint32_t lsbs = (uint32_t)(r.buf >> ((64 - total) & 63)) & ((1u << k) - 1);
+			const uint32_t uf = (z << k) | lsbs;
+			int32_t res = fast ? (int32_t)((uf >> 1) ^ (0u - (uf & 1))) : h.constant;
+			const uint32_t used = fast ? total : 0;
+			r.buf <<= used;
+			r.avail -= used;
+			r.bpos += used;
+			if (!fast && i < work_end) {
+				if (h.kind >= 2) {
+					if (i < h.order)
+						res = L.w[i][lane];
+					else {
+						if (i == next_part) {
+							k = br_get(r, h.plen);
+							escape = k >= h.pesc;
+							if (escape)
+								raw_bits = br_get(r, 5);
+							next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
+							seg_lo = i + 1;
+							seg_len = escape ? 0 : next_part - seg_lo;
+							if (escape)
+								k = 0;
+						}
+						if (!escape) {
+							const uint32_t msbs = br_unary(r);
+							const uint32_t low = br_get(r, k);
+							const uint32_t u = (msbs << k) | low;
+							res = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+						} else
+							res = br_get_signed(r, raw_bits);
 					}
-					v = (int32_t)((uint32_t)v + (uint32_t)pred);
+				} else
+					res = br_get_signed(r, h.sbps);
+				br_refill(r);
+				if (r.err) {
+					work_end = 0;
+					seg_len = 0;
 				}
 			}
-			if (M > 0 && predictive) {
+			int32_t v = res;
+			if (M > 0) {
+				int32_t pred;
+				if (WIDE) {
+					int64_t sum = 0;
+#pragma unroll
+					for (int j = 0; j < M; j++)
+						sum += (int64_t)q[j] * (int64_t)hist[j];
+					pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
+				} else {
+					int32_t sum = 0;
+#pragma unroll
+					for (int j = 0; j < M; j++)
+						sum += MUL24 ? __mul24(q[j], hist[j]) : q[j] * hist[j];
+					pred = sum >> h.shift;
+				}
+				// warm-up samples are stored as they are; lanes without a predictor have q = 0
+				v = (int32_t)((uint32_t)res + (i >= h.order ? (uint32_t)pred : 0u));
 #pragma unroll
 				for (int j = M - 1; j > 0; j--)
 					hist[j] = hist[j - 1];
 				hist[0] = v;
 			}
-			L.out[(i - i0) * LW + lane] = (int32_t)((uint32_t)v << h.wasted);
+			slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
+			// top the window up to 33..64 bits
+			{
+				const bool c = r.avail <= 32;
+				const uint64_t add = (uint64_t)r.nxt << ((32 - r.avail) & 63);
+				r.buf |= c ? add : 0ull;
+				r.avail += c ? 32u : 0u;
+				r.nxt = c ? __builtin_bswap32(ring_word) : r.nxt;
+				r.wrel += c ? 1u : 0u;
+			}
 		}
 		// the block goes out with all 64 threads along memory order
-		for (uint32_t e = tid; e < (iend - i0) * LW; e += DEC_LANES)
+		const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
+		for (uint32_t e = tid; e < nblk; e += DEC_LANES)
 			plane[(size_t)i0 * LW + e] = L.out[e];
 	}
 }
@@ -516,23 +575,31 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	else {
 		cd.pos = 0; cd.sample = 0; cd.hdr_bytes = 0; cd.blocksize = 0; cd.assignment = 0; cd.stream = 0; cd.status = 0; cd.end_byte = 0;
 	}
+	const uint64_t nwords = (P.flac_bytes + 3) / 4;
 	BitRd r;
-	r.w = flac_words;
-	r.nwords = (P.flac_bytes + 3) / 4;
-	r.end = live ? (streams[cd.stream].byte_offset + streams[cd.stream].byte_length) * 8 : 0;
 	r.wbase = cd.pos >> 2;
-	r.loaded = 0;
+	r.wg = flac_words + r.wbase;
+	r.nrel = nwords - r.wbase > 0xffffffffull ? 0xffffffffu : (uint32_t)(nwords - r.wbase);
+	// positions are 32-bit, relative to the frame's first word; a stream that goes on for more
+	// than that is treated as endless
+	bool endless = false;
+	{
+		const uint64_t end_abs = live ? (streams[cd.stream].byte_offset + streams[cd.stream].byte_length) * 8 : 0;
+		const uint64_t rel = end_abs > r.wbase * 32 ? end_abs - r.wbase * 32 : 0;
+		endless = rel > 0xf0000000ull;
+		r.bend = endless ? 0xf0000000u : (uint32_t)rel;
+	}
 	r.ring = L.ring[lane];
 	// the first two chunks of every frame, all requested before the first is waited for
 	{
 		uint32_t first[2 * DEC_MAXLW];
 #pragma unroll
 		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
-			const uint64_t wb = ((uint64_t)(uint32_t)__shfl((int)(r.wbase >> 32), (int)ln, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)r.wbase, (int)ln, 64);
+			const uint64_t wb = ((uint64_t)wave_value((uint32_t)(r.wbase >> 32), (int)ln) << 32) | wave_value((uint32_t)r.wbase, (int)ln);
 #pragma unroll
 			for (uint32_t c = 0; c < 2; c++) {
 				const uint64_t at = wb + c * RING_CHUNK + tid;
-				first[2 * ln + c] = (ln < LW && at < r.nwords) ? flac_words[at] : 0u;
+				first[2 * ln + c] = (ln < LW && at < nwords) ? flac_words[at] : 0u;
 			}
 		}
 #pragma unroll
@@ -540,13 +607,13 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 			L.ring[ln][tid] = first[2 * ln];
 			L.ring[ln][RING_CHUNK + tid] = first[2 * ln + 1];
 		}
-		r.loaded = 2;
+		r.limit = 2 * RING_CHUNK;
 	}
 	Pump pm;
 	pm.lane[0] = pm.lane[1] = -1;
 	pm.data[0] = pm.data[1] = 0;
 	pm.half[0] = pm.half[1] = 0;
-	br_start(r, (cd.pos + cd.hdr_bytes) * 8);
+	br_start(r, ((uint32_t)cd.pos & 3) * 8 + cd.hdr_bytes * 8);
 	const uint32_t bsf = cd.blocksize;
 	uint32_t bs_w = bsf;
 #pragma unroll
@@ -558,7 +625,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 
 	for (uint32_t c = 0; c < P.channels; c++) {
 		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
-		pump_service(pm, r, L, tid, live);
+		pump_service(pm, r, L, tid, live, nwords);
 		// ---- subframe header (stream_decoder.c:2450-2518) ----
 		SubHdr h;
 		h.kind = 0; h.order = 0; h.wasted = 0; h.po = 0; h.plen = 4; h.pesc = 15; h.psize = 0; h.shift = 0; h.lane_wide = false; h.constant = 0;
@@ -627,6 +694,8 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 				if (h.po > 0 && (h.psize < h.order || (h.psize << h.po) != bsf))
 					r.err = true;
 			}
+			if (r.bpos > r.bend)
+				r.err = true;
 		}
 		// ---- samples, dispatched on what the wave as a whole needs ----
 		const bool predictive = h.kind >= 2 && live && !r.err;
@@ -641,9 +710,9 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		const bool run = live && !r.err;
 #define DECODE(M) \
 	do { \
-		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
-		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
-		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run); \
+		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
 	} while (0)
 		if (need == 0) DECODE(0);
 		else if (need <= 4) DECODE(4);
@@ -654,19 +723,21 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 #undef DECODE
 	}
 	if (live) {
+		if (r.bpos > r.bend)
+			r.err = true;
 		// read_zero_padding_ (stream_decoder.c:2773): the pad bits must be zero
-		if (!r.err && (r.pos & 7)) {
-			const uint32_t n = 8 - ((uint32_t)r.pos & 7);
+		if (!r.err && (r.bpos & 7)) {
+			const uint32_t n = 8 - (r.bpos & 7);
 			if (br_get(r, n) != 0)
 				r.err = true;
 		}
-		const uint64_t end_byte = (r.pos >> 3) + 2;
-		if (end_byte * 8 > r.end)
+		const uint64_t end_byte = r.wbase * 4 + (r.bpos >> 3) + 2;
+		const bool past = !endless && ((r.bpos > r.bend) || ((uint64_t)(r.bpos >> 3) + 2) * 8 > r.bend);
+		if (past)
 			r.err = true;
 		cands[j].end_byte = end_byte;
 		// a parse that ran off the end of the input is a cut-off frame, not a malformed one
-		const bool cut = r.pos > r.end || end_byte * 8 > r.end;
-		cands[j].status = cut ? 4u : r.err ? 2u : 1u;
+		cands[j].status = past ? 4u : r.err ? 2u : 1u;
 	}
 }
 
