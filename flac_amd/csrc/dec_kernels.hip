@@ -440,19 +440,21 @@ template <int M, bool WIDE, bool MUL24>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, DecLds &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
                                                uint32_t bsf, bool live, uint64_t nwords)
 {
+	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
+	// are switched on at the first residual; lanes without a predictor keep zeros
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
-	const bool predictive = h.kind >= 2;
 	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
 #pragma unroll
 	for (int j = 0; j < M; j++) {
-		q[j] = ((uint32_t)j < h.order && predictive && tid < DEC_MAXLW) ? L.q[j][lane] : 0;
+		q[j] = 0;
 		hist[j] = 0;
 	}
 	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
-	uint32_t k = 0, raw_bits = 0;
+	uint32_t k = 0, kmask = 0, raw_bits = 0;
 	bool escape = false;
-	// samples [seg_lo, seg_lo + seg_len) are plain Rice symbols with parameter k
-	uint32_t seg_lo = 0, seg_len = 0;
+	// samples below seg_end are plain Rice symbols with parameter k; fast_end is seg_end while
+	// the ring is sure to hold every word the rest of the block can ask for, else 0
+	uint32_t seg_end = 0, fast_end = 0;
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
 	br_refill(r);
@@ -463,8 +465,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		if (r.bpos > r.bend) {
 			r.err = true;
 			work_end = 0;
-			seg_len = 0;
+			seg_end = 0;
 		}
+		// the fast path takes at most two words per sample
+		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 #pragma unroll 4
 		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
 			const uint32_t i = i0 + s;
@@ -472,10 +476,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			const uint32_t ring_word = r.ring[r.wrel & (RING_WORDS - 1)];
 			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the window
 			const uint32_t hi = (uint32_t)(r.buf >> 32);
-			const uint32_t z = (uint32_t)__clz((int)hi);  // 32 when hi is 0
+			const uint32_t z = (uint32_t)__builtin_clz(hi | (hi == 0));  // unused when hi is 0
 			const uint32_t total = z + 1 + k;
-			const bool fast = (i - seg_lo) < seg_len && hi != 0 && total <= r.avail && r.wrel < r.limit;
-			const uint32_t lsbs = (uint32_t)(r.buf >> ((64 - total) & 63)) & ((1u << k) - 1);
+			const bool fast = i < fast_end && hi != 0 && total <= r.avail;
+			const uint32_t lsbs = (uint32_t)(r.buf >> ((64 - total) & 63)) & kmask;
 			const uint32_t uf = (z << k) | lsbs;
 			int32_t res = fast ? (int32_t)((uf >> 1) ^ (0u - (uf & 1))) : h.constant;
 			const uint32_t used = fast ? total : 0;
@@ -488,15 +492,20 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 						res = L.w[i][lane];
 					else {
 						if (i == next_part) {
+							if (M > 0 && i == h.order) {
+#pragma unroll
+								for (int j = 0; j < M; j++)
+									q[j] = (uint32_t)j < h.order ? L.q[j][lane] : 0;
+							}
 							k = br_get(r, h.plen);
 							escape = k >= h.pesc;
-							if (escape)
+							if (escape) {
 								raw_bits = br_get(r, 5);
-							next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
-							seg_lo = i + 1;
-							seg_len = escape ? 0 : next_part - seg_lo;
-							if (escape)
 								k = 0;
+							}
+							kmask = (1u << k) - 1;
+							next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
+							seg_end = escape ? 0 : next_part;
 						}
 						if (!escape) {
 							const uint32_t msbs = br_unary(r);
@@ -511,8 +520,9 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				br_refill(r);
 				if (r.err) {
 					work_end = 0;
-					seg_len = 0;
+					seg_end = 0;
 				}
+				fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 			}
 			int32_t v = res;
 			if (M > 0) {
@@ -530,8 +540,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 						sum += MUL24 ? __mul24(q[j], hist[j]) : q[j] * hist[j];
 					pred = sum >> h.shift;
 				}
-				// warm-up samples are stored as they are; lanes without a predictor have q = 0
-				v = (int32_t)((uint32_t)res + (i >= h.order ? (uint32_t)pred : 0u));
+				v = (int32_t)((uint32_t)res + (uint32_t)pred);
 #pragma unroll
 				for (int j = M - 1; j > 0; j--)
 					hist[j] = hist[j - 1];
@@ -541,8 +550,8 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			// top the window up to 33..64 bits
 			{
 				const bool c = r.avail <= 32;
-				const uint64_t add = (uint64_t)r.nxt << ((32 - r.avail) & 63);
-				r.buf |= c ? add : 0ull;
+				const uint64_t add = (uint64_t)(c ? r.nxt : 0u) << ((32 - r.avail) & 63);
+				r.buf |= add;
 				r.avail += c ? 32u : 0u;
 				r.nxt = c ? __builtin_bswap32(ring_word) : r.nxt;
 				r.wrel += c ? 1u : 0u;
