@@ -103,35 +103,59 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(PkShared &S, uint32_t v
 	return off + inc - v;
 }
 
+// a * m modulo the polynomial, for a multiplier that is the same in every lane: the lane's own
+// operand is only bit-tested, the shifting and reducing of m runs on the scalar unit
+__device__ __forceinline__ uint32_t gf16_mul_by(uint32_t a, uint32_t m_uniform)
+{
+	uint32_t r = 0, m = m_uniform;
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		r ^= (0u - ((a >> i) & 1u)) & m;
+		m <<= 1;
+		if (m & 0x10000)
+			m ^= 0x18005;
+	}
+	return r;
+}
+
 // CRC-16 of nbytes bytes that start at window word 0 (FLAC__crc16, crc.c:134): each thread takes an
 // equal run of bytes, the runs are right-aligned (leading virtual zeros do not change a CRC that
-// starts at 0), and a tree folds them with multiplications by powers of x.
+// starts at 0), and a tree folds them with multiplications by powers of x: six levels inside each
+// wave by lane shuffles, the four wave results by Horner's rule.  nbytes is the same in all threads.
 __device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
 {
-	const uint32_t tid = threadIdx.x;
-	const uint32_t R = (nbytes + FA_THREADS - 1) / FA_THREADS;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nbytes + FA_THREADS - 1) / FA_THREADS));
 	uint32_t crc = 0;
 	if (R) {
-		const int64_t start = (int64_t)nbytes - (int64_t)(FA_THREADS - tid) * R;
+		const int32_t start = (int32_t)nbytes - (int32_t)((FA_THREADS - tid) * R);
 		for (uint32_t i = 0; i < R; i++) {
-			const int64_t b = start + i;
+			const int32_t b = start + (int32_t)i;
 			if (b >= 0) {
 				const uint32_t byte = (S.W[b >> 2] >> (24 - 8 * (b & 3))) & 0xff;
 				crc = ((crc << 8) & 0xffff) ^ S.crc_table[(crc >> 8) ^ byte];
 			}
 		}
 	}
-	S.crcs[tid] = crc;
-	__syncthreads();
-	uint32_t m = gf16_xpow8(R);
-	for (uint32_t L = 0; L < 8; L++) {
+	uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)gf16_xpow8(R));
+#pragma unroll
+	for (uint32_t L = 0; L < 6; L++) {
 		const uint32_t mask = (2u << L) - 1;
-		if ((tid & mask) == mask)
-			S.crcs[tid] = gf16_mul(S.crcs[tid - (1u << L)], m) ^ S.crcs[tid];
-		m = gf16_mul(m, m);
-		__syncthreads();
+		const uint32_t below = __shfl_up(crc, 1u << L, 64);
+		const uint32_t folded = gf16_mul_by(below, m) ^ crc;
+		if ((lane & mask) == mask)
+			crc = folded;
+		m = (uint32_t)__builtin_amdgcn_readfirstlane((int)gf16_mul(m, m));
 	}
-	const uint32_t out = S.crcs[FA_THREADS - 1];
+	__syncthreads();
+	if (lane == 63)
+		S.crcs[wv] = crc;
+	__syncthreads();
+	// m is now x^(8 * 64 R): one wave's worth of bytes
+	uint32_t out = S.crcs[0];
+#pragma unroll
+	for (uint32_t w = 1; w < FA_THREADS / 64; w++)
+		out = gf16_mul_by(out, m) ^ S.crcs[w];
 	__syncthreads();
 	return out;
 }
@@ -177,11 +201,10 @@ __device__ __forceinline__ void drain(PkShared &S, uint32_t *slot, uint32_t slot
 		__syncthreads();
 		const uint32_t end_word = end_bit >> 5;  // first word that is not complete yet
 		const uint32_t bw = S.base_word;
-		if (end_word <= bw + PK_CAPW - 1) {
-			// everything fits: flush the complete words, keep the partial one
-			flush_window(S, slot, slot_words, end_word - bw, true, true);
+		// everything so far is inside the window, with a word to spare for the frame CRC: it goes out
+		// when the window fills or the frame ends
+		if (end_word + 2 <= bw + PK_CAPW)
 			return;
-		}
 		flush_window(S, slot, slot_words, PK_CAPW, false, true);
 	}
 }
