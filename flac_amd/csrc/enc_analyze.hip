@@ -167,35 +167,111 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 
 // ---------------------------------------------------------------------------------------------
 // k_autoc: FLAC__lpc_window_data (lpc.c:56) + FLAC__lpc_compute_autocorrelation (lpc.c:63).
-// The reference adds the products of one lag in sample order into a float accumulator; each
-// (task, lag) lane here walks the samples in that same order, so the sums are the same floats.
-// Samples are staged through LDS in tiles; positions past the frame are zero, and adding the
-// resulting +-0 products leaves an accumulator unchanged.
+// The reference adds the products of one lag in sample order into a float accumulator; a lane
+// here does the same for its lags, so the sums are the same floats.
+//
+// Tasks (frame, signal, apodization) are taken two at a time: the windowed samples of a task pair
+// sit interleaved in LDS, {a[k], b[k]}, so that one packed multiply and one packed add advance the
+// same lag of both tasks.  A lane owns lags 2g and 2g+1 of its pair and walks the samples two
+// steps per iteration: one 16-byte read for x[i], x[i+1], one for the next two of the sliding
+// x[i+2g ..] window.  Positions past the frame are zero, and adding the resulting +-0 products
+// leaves an accumulator unchanged.
+//
+// Tiles of AC_T steps are double-buffered: the global loads for the next tile are in flight while
+// the current one is computed.  16-bit stereo with mid/side and a single window (the common case)
+// has a dedicated staging path in which one 32-bit load yields the sample of all four signals of a
+// frame, i.e. of two task pairs.
 // ---------------------------------------------------------------------------------------------
-#define AC_TILE 256
-#define AC_MAXTASKS 16
-// Row stride AC_TILE + lag: AC_TILE is a multiple of 32, so lane (task j, lag l) = thread j*lag + l
-// reads bank (thread + sample) mod 32 and a half-wave never collides.
-#define AC_LDS_FLOATS (AC_MAXTASKS * (AC_TILE + FA_MAX_ORDER + 1))
+#define AC_T 64           // steps per tile
+#define AC_MAXROWS 36     // task pairs per workgroup at most (even)
+#define AC_FPW 5          // frames per wave in the dedicated staging path: ceil(AC_MAXROWS / 2 / 4)
+#define AC_NK 2           // 64-lane strips per row: AC_T + 2 * ceil(33 / 2) <= 128
+
+typedef float fa_f2 __attribute__((ext_vector_type(2)));
+typedef float fa_f4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
-                                                       const float *windows, float *autoc, uint32_t tasks_per_block)
+                                                       const float *windows, float *autoc, uint32_t rows_per_block, uint32_t G)
 {
-	__shared__ float x[AC_LDS_FLOATS];
+	extern __shared__ __attribute__((aligned(16))) float xs[];
 	const uint32_t lag = P.max_lpc_order + 1;
-	const uint32_t row_len = AC_TILE + lag;
-	const uint32_t tid = threadIdx.x;
+	const uint32_t row_pairs = AC_T + 2 * G;
+	const uint32_t buf_floats = rows_per_block * row_pairs * 2;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
-	const uint32_t task0 = blockIdx.x * tasks_per_block;
-	const uint32_t my_j = tid / lag, my_l = tid % lag;
-	const bool active = my_j < tasks_per_block && task0 + my_j < ntasks;
-	float acc = 0.0f;
+	const uint32_t nrows = (ntasks + 1) / 2;
+	const uint32_t row0 = blockIdx.x * rows_per_block;
+	const uint32_t my_j = tid / G, my_g = tid % G;
+	const bool active = my_j < rows_per_block && row0 + my_j < nrows;
+	const bool quad = B.pairs && P.nsignals == 4 && P.napod == 1;  // rows 2f, 2f+1 = (L,R), (M,S) of frame f
+	const uint32_t ntiles = (P.blocksize + AC_T - 1) / AC_T;
+	const uint32_t frames_pb = rows_per_block / 2, frame0 = row0 / 2;
 
-	for (uint32_t c0 = 0; c0 < P.blocksize; c0 += AC_TILE) {
-		// stage tile [c0, c0 + AC_TILE + lag) of every task's windowed signal
-		for (uint32_t e = tid; e < tasks_per_block * row_len; e += FA_THREADS) {
-			const uint32_t j = e / row_len, k = e % row_len;
-			const uint32_t task = task0 + j;
+	// dedicated path: per frame of this wave, its length and the four wasted-bit counts
+	uint32_t q_bsf[AC_FPW], q_wasted[AC_FPW];
+	if (quad) {
+#pragma unroll
+		for (uint32_t n = 0; n < AC_FPW; n++) {
+			const uint32_t fi = wv + 4 * n, f = frame0 + fi;
+			q_bsf[n] = 0;
+			q_wasted[n] = 0;
+			if (fi < frames_pb && f < B.nframes) {
+				q_bsf[n] = frame_len(B, P.blocksize, f);
+				const FaSubStat *st = stats + (size_t)f * 4;
+				q_wasted[n] = st[0].wasted | (st[1].wasted << 8) | (st[2].wasted << 16) | (st[3].wasted << 24);
+			}
+		}
+	}
+	uint32_t q_w[AC_FPW][AC_NK];
+	float q_win[AC_FPW][AC_NK];
+	auto quad_load = [&](uint32_t tile) {
+		const uint32_t c0 = tile * AC_T;
+#pragma unroll
+		for (uint32_t n = 0; n < AC_FPW; n++) {
+			const uint32_t f = frame0 + wv + 4 * n;
+#pragma unroll
+			for (uint32_t m = 0; m < AC_NK; m++) {
+				const uint32_t idx = c0 + lane + 64 * m;
+				const uint32_t ci = q_bsf[n] ? umin32(idx, q_bsf[n] - 1) : 0;
+				q_w[n][m] = q_bsf[n] ? ((const uint32_t *)pcm)[(uint64_t)f * P.blocksize + ci] : 0u;
+				q_win[n][m] = windows[umin32(idx, P.blocksize - 1)];
+			}
+		}
+	};
+	auto quad_store = [&](uint32_t tile, float *dst) {
+		const uint32_t c0 = tile * AC_T;
+#pragma unroll
+		for (uint32_t n = 0; n < AC_FPW; n++) {
+			const uint32_t fi = wv + 4 * n;
+			if (fi >= frames_pb)
+				continue;
+#pragma unroll
+			for (uint32_t m = 0; m < AC_NK; m++) {
+				const uint32_t k = lane + 64 * m;
+				if (k >= row_pairs)
+					continue;
+				fa_f2 lr = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
+				if (c0 + k < q_bsf[n]) {
+					const uint32_t w = q_w[n][m];
+					const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
+					const float win = q_win[n][m];
+					lr.x = __fmul_rn((float)(l >> (q_wasted[n] & 0xff)), win);
+					lr.y = __fmul_rn((float)(r >> ((q_wasted[n] >> 8) & 0xff)), win);
+					ms.x = __fmul_rn((float)(((l + r) >> 1) >> ((q_wasted[n] >> 16) & 0xff)), win);
+					ms.y = __fmul_rn((float)((l - r) >> (q_wasted[n] >> 24)), win);
+				}
+				*(fa_f2 *)(dst + ((size_t)(2 * fi) * row_pairs + k) * 2) = lr;
+				*(fa_f2 *)(dst + ((size_t)(2 * fi + 1) * row_pairs + k) * 2) = ms;
+			}
+		}
+	};
+	// general path: any format, element by element
+	auto plain_stage = [&](uint32_t tile, float *dst) {
+		const uint32_t c0 = tile * AC_T;
+		for (uint32_t e = tid; e < buf_floats; e += FA_THREADS) {
+			const uint32_t h = e & 1, pk = e >> 1;
+			const uint32_t j = pk / row_pairs, k = pk % row_pairs;
+			const uint32_t task = 2 * (row0 + j) + h;
 			float v = 0.0f;
 			if (task < ntasks) {
 				const uint32_t sub = task / P.napod, a = task % P.napod;
@@ -207,19 +283,63 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 					v = __fmul_rn((float)smp, windows[(size_t)a * P.blocksize + idx]);
 				}
 			}
-			x[e] = v;
+			dst[e] = v;
 		}
-		__syncthreads();
+	};
+
+	if (quad) {
+		quad_load(0);
+		quad_store(0, xs);
+	} else
+		plain_stage(0, xs);
+	__syncthreads();
+
+	fa_f2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+	for (uint32_t t = 0; t < ntiles; t++) {
+		const float *cur_buf = xs + (t & 1) * buf_floats;
+		float *next_buf = xs + ((t + 1) & 1) * buf_floats;
+		const bool more = t + 1 < ntiles;
+		if (more && quad)
+			quad_load(t + 1);
 		if (active) {
-			const float *row = x + my_j * row_len;
-#pragma unroll 8
-			for (uint32_t sidx = 0; sidx < AC_TILE; sidx++)
-				acc = __fadd_rn(acc, __fmul_rn(row[sidx], row[sidx + my_l]));
+			const float *row = cur_buf + (size_t)my_j * row_pairs * 2;
+			fa_f4 win = *(const fa_f4 *)(row + 4 * my_g);  // pairs 2g, 2g+1
+#pragma unroll 4
+			for (uint32_t i = 0; i < AC_T; i += 2) {
+				const fa_f4 a = *(const fa_f4 *)(row + 2 * i);                    // pairs i, i+1
+				const fa_f4 nx = *(const fa_f4 *)(row + 2 * i + 4 * my_g + 4);   // pairs i+2g+2, i+2g+3
+				const fa_f2 a0 = {a.x, a.y}, a1 = {a.z, a.w};
+				const fa_f2 b0 = {win.x, win.y}, b1 = {win.z, win.w}, b2 = {nx.x, nx.y};
+				acc0 = acc0 + a0 * b0;
+				acc1 = acc1 + a0 * b1;
+				acc0 = acc0 + a1 * b1;
+				acc1 = acc1 + a1 * b2;
+				win = nx;
+			}
+		}
+		if (more) {
+			if (quad)
+				quad_store(t + 1, next_buf);
+			else
+				plain_stage(t + 1, next_buf);
 		}
 		__syncthreads();
 	}
-	if (active)
-		autoc[(size_t)(task0 + my_j) * (FA_MAX_ORDER + 1) + my_l] = acc;
+	if (active) {
+		const uint32_t task = 2 * (row0 + my_j);
+		float *o = autoc + (size_t)task * (FA_MAX_ORDER + 1);
+		const uint32_t l0 = 2 * my_g, l1 = l0 + 1;
+		if (l0 < lag)
+			o[l0] = acc0.x;
+		if (l1 < lag)
+			o[l1] = acc1.x;
+		if (task + 1 < ntasks) {
+			if (l0 < lag)
+				o[FA_MAX_ORDER + 1 + l0] = acc0.y;
+			if (l1 < lag)
+				o[FA_MAX_ORDER + 1 + l1] = acc1.y;
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,11 +654,15 @@ void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, co
                      hipStream_t st)
 {
 	const uint32_t lag = P.max_lpc_order + 1;
-	uint32_t tpb = FA_THREADS / lag;
-	if (tpb > AC_MAXTASKS)
-		tpb = AC_MAXTASKS;
+	const uint32_t G = (lag + 1) / 2;  // lag pairs per task pair
+	uint32_t rows = FA_THREADS / G;
+	if (rows > AC_MAXROWS)
+		rows = AC_MAXROWS;
+	rows &= ~1u;
 	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
-	hipLaunchKernelGGL(k_autoc, dim3((ntasks + tpb - 1) / tpb), dim3(FA_THREADS), 0, st, P, B, pcm, stats, windows, autoc, tpb);
+	const uint32_t nrows = (ntasks + 1) / 2;
+	const size_t lds = (size_t)2 * rows * (AC_T + 2 * G) * 2 * sizeof(float);
+	hipLaunchKernelGGL(k_autoc, dim3((nrows + rows - 1) / rows), dim3(FA_THREADS), lds, st, P, B, pcm, stats, windows, autoc, rows, G);
 }
 
 void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stats, const float *autoc, FaLpcCand *cands, int32_t *coefs,

@@ -205,6 +205,11 @@ __device__ __forceinline__ void drain(PkShared &S, uint32_t *slot, uint32_t slot
 		// when the window fills or the frame ends
 		if (end_word + 2 <= bw + PK_CAPW)
 			return;
+		if (end_word < bw + PK_CAPW) {
+			// all of this tile's bits are in, but the window is nearly full: make room
+			flush_window(S, slot, slot_words, end_word - bw, true, true);
+			return;
+		}
 		flush_window(S, slot, slot_words, PK_CAPW, false, true);
 	}
 }
