@@ -166,6 +166,190 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_analyze_quad: the same statistics for 16-bit stereo with mid/side, all four signals of a frame
+// in one workgroup.  One 32-bit word holds a wide sample; it is loaded and staged once, and left,
+// right, mid and side are formed in registers.  The sums are kept modulo 2^32, which is all the
+// reference's 32-bit accumulators hold (fixed.c:234); streams that need the 64-bit variant take
+// k_analyze.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v += (uint32_t)__shfl_xor((int)v, o, 64);
+	return v;
+}
+
+__device__ __forceinline__ void quad_split(uint32_t w, int32_t (&x)[4])
+{
+	const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
+	x[0] = l;
+	x[1] = r;
+	x[2] = (l + r) >> 1;
+	x[3] = l - r;
+}
+
+__global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
+{
+	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);
+	const uint32_t *words = (const uint32_t *)pcm + (uint64_t)f * P.blocksize;
+	__shared__ uint32_t sh_or[4][4], sh_ne[4][4];
+	__shared__ uint32_t sh_te[4][4][5];
+	__shared__ uint32_t stage[ST_WORDS(4)];
+	constexpr uint32_t HP = ST_HP(4);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+
+	int32_t first[4];
+	quad_split(words[0], first);
+	uint32_t orv[4] = {0, 0, 0, 0}, ne[4] = {0, 0, 0, 0};
+	// pass 1: OR of all samples (wasted bits) and whether they are all equal; tile 0 stays staged
+	for (uint32_t t0 = 0; t0 < bsf; t0 += FA_TILE) {
+		uint32_t w[NIT];
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			int32_t idx = (int32_t)(t0 + j) - (int32_t)HP;
+			idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+			w[i] = words[idx];
+		}
+		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			const bool inside = j >= HP && t0 + j - HP < bsf;
+			const uint32_t ww = inside ? w[i] : (first[0] & 0xffff) | ((uint32_t)first[1] << 16);
+			int32_t x[4];
+			quad_split(ww, x);
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				orv[s] |= (uint32_t)x[s];
+				ne[s] |= (uint32_t)(x[s] != first[s]);
+			}
+			if (t0 == 0 && j < n0)
+				stage[j + (j >> 4)] = inside ? w[i] : 0u;
+		}
+	}
+	// samples outside the frame were replaced by the first sample above; that one is inside anyway
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		orv[s] = wave_or(orv[s]);
+		ne[s] = wave_or(ne[s]);
+		if ((tid & 63) == 0) {
+			sh_or[tid >> 6][s] = orv[s];
+			sh_ne[tid >> 6][s] = ne[s];
+		}
+	}
+	__syncthreads();
+	uint32_t wasted[4];
+#pragma unroll
+	for (int s = 0; s < 4; s++) {
+		orv[s] = sh_or[0][s] | sh_or[1][s] | sh_or[2][s] | sh_or[3][s];
+		ne[s] = sh_ne[0][s] | sh_ne[1][s] | sh_ne[2][s] | sh_ne[3][s];
+		wasted[s] = orv[s] ? (uint32_t)__ffs((int)orv[s]) - 1u : 0u;
+	}
+
+	uint32_t te[4][5];
+#pragma unroll
+	for (int s = 0; s < 4; s++)
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			te[s][k] = 0;
+	if (bsf >= 4) {
+		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
+			if (tile > 0) {
+				__syncthreads();
+				uint32_t w[NIT];
+#pragma unroll
+				for (uint32_t i = 0; i < NIT; i++) {
+					const uint32_t j = tid + i * FA_THREADS;
+					int32_t idx = (int32_t)(tile * FA_TILE + j) - (int32_t)HP;
+					idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+					w[i] = words[idx];
+				}
+				const uint32_t n = HP + ((umin32(bsf - tile * FA_TILE, FA_TILE) + 15) & ~15u);
+#pragma unroll
+				for (uint32_t i = 0; i < NIT; i++) {
+					const uint32_t j = tid + i * FA_THREADS;
+					const uint32_t idx = tile * FA_TILE + j - HP;
+					if (j < n)
+						stage[j + (j >> 4)] = idx < bsf ? w[i] : 0u;
+				}
+				__syncthreads();
+			}
+			const uint32_t base = tile * FA_TILE + tid * FA_CHUNK;
+			if (base >= bsf)
+				continue;
+			int32_t raw[4 + FA_CHUNK];
+			load_chunk_lds<4>(raw, (const int32_t *)stage);
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				uint32_t d[4 + FA_CHUNK];
+#pragma unroll
+				for (int k = 0; k < 4 + FA_CHUNK; k++) {
+					int32_t x[4];
+					quad_split((uint32_t)raw[k], x);
+					d[k] = (uint32_t)(x[s] >> wasted[s]);
+				}
+#pragma unroll
+				for (int i = 0; i < FA_CHUNK; i++) {
+					const uint32_t idx = base + i;
+					if (idx >= 4 && idx < bsf) {
+						const uint32_t a = d[4 + i], b = d[3 + i], c = d[2 + i], e = d[1 + i], g = d[i];
+						te[s][0] += abs32((int32_t)a);
+						te[s][1] += abs32((int32_t)(a - b));
+						te[s][2] += abs32((int32_t)(a - 2 * b + c));
+						te[s][3] += abs32((int32_t)(a - 3 * b + 3 * c - e));
+						te[s][4] += abs32((int32_t)(a - 4 * b + 6 * c - 4 * e + g));
+					}
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int s = 0; s < 4; s++)
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			const uint32_t v = wave_sum32(te[s][k]);
+			if ((tid & 63) == 0)
+				sh_te[tid >> 6][s][k] = v;
+		}
+	__syncthreads();
+	if (tid < 4) {
+		const uint32_t s = tid;
+		const uint32_t ws = s == 0 ? wasted[0] : s == 1 ? wasted[1] : s == 2 ? wasted[2] : wasted[3];
+		const uint32_t nes = s == 0 ? ne[0] : s == 1 ? ne[1] : s == 2 ? ne[2] : ne[3];
+		const int32_t fs = s == 0 ? first[0] : s == 1 ? first[1] : s == 2 ? first[2] : first[3];
+		FaSubStat st;
+		st.wasted = ws;
+		st.bps = P.bps - ws + (s == 3 ? 1u : 0u);
+		st.first_sample = fs >> ws;
+		st.is_constant = 0;
+		st.fixed_guess = 0;
+		for (int k = 0; k < 5; k++)
+			st.rbps[k] = 0.0f;
+		if (bsf >= 4) {
+			uint64_t t[5];
+			for (int k = 0; k < 5; k++)
+				t[k] = (uint32_t)(sh_te[0][s][k] + sh_te[1][s][k] + sh_te[2][s][k] + sh_te[3][s][k]);
+			auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
+			uint32_t order;
+			if (t[0] < mn(mn(mn(t[1], t[2]), t[3]), t[4])) order = 0;
+			else if (t[1] < mn(mn(t[2], t[3]), t[4])) order = 1;
+			else if (t[2] < mn(t[3], t[4])) order = 2;
+			else if (t[3] < t[4]) order = 3;
+			else order = 4;
+			st.fixed_guess = order;
+			const double n = (double)(bsf - 4);
+			for (int k = 0; k < 5; k++)
+				st.rbps[k] = (float)(t[k] > 0 ? log(M_LN2 * (double)t[k] / n) / M_LN2 : 0.0);
+			st.is_constant = (!P.disable_constant && st.rbps[1] == 0.0f && nes == 0) ? 1u : 0u;
+		}
+		stats[(size_t)f * 4 + s] = st;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_autoc: FLAC__lpc_window_data (lpc.c:56) + FLAC__lpc_compute_autocorrelation (lpc.c:63).
 // The reference adds the products of one lag in sample order into a float accumulator; a lane
 // here does the same for its lags, so the sums are the same floats.
@@ -647,7 +831,10 @@ __global__ __launch_bounds__(FA_THREADS) void k_compact(const uint32_t *slots, u
 // ---------------------------------------------------------------------------------------------
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_analyze, dim3(B.nframes * P.nsignals), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
+	if (B.pairs && P.nsignals == 4 && !P.wide_fixed)
+		hipLaunchKernelGGL(k_analyze_quad, dim3(B.nframes), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
+	else
+		hipLaunchKernelGGL(k_analyze, dim3(B.nframes * P.nsignals), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
 }
 
 void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,
