@@ -328,11 +328,22 @@ __device__ __forceinline__ void lpc_pred16_dot2(const int32_t (&P)[HIST + FA_CHU
                                                 int32_t (&pred)[FA_CHUNK])
 {
 	int32_t sum[FA_CHUNK];
+	if (order == 0) {
 #pragma unroll
-	for (int i = 0; i < FA_CHUNK; i++)
-		sum[i] = 0;
+		for (int i = 0; i < FA_CHUNK; i++)
+			pred[i] = 0;
+		return;
+	}
+	{
+		// the first pair of taps starts the sums (three-operand form with a literal zero: no
+		// separate clearing of 16 registers per candidate)
+		const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[0]);
 #pragma unroll
-	for (int jj = 0; jj < (MAXORDER + 1) / 2; jj++) {
+		for (int i = 0; i < FA_CHUNK; i++)
+			asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(sum[i]) : "v"(P[HIST + i - 2]), "s"(qv));
+	}
+#pragma unroll
+	for (int jj = 1; jj < (MAXORDER + 1) / 2; jj++) {
 		if ((uint32_t)(2 * jj) < order) {
 			const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[jj]);
 #pragma unroll
@@ -340,9 +351,15 @@ __device__ __forceinline__ void lpc_pred16_dot2(const int32_t (&P)[HIST + FA_CHU
 				sum[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, P[HIST + i - 2 - 2 * jj]), __builtin_bit_cast(fa_short2, qv), sum[i], false);
 		}
 	}
+	if (shift) {
 #pragma unroll
-	for (int i = 0; i < FA_CHUNK; i++)
-		pred[i] = sum[i] >> shift;
+		for (int i = 0; i < FA_CHUNK; i++)
+			pred[i] = sum[i] >> shift;
+	} else {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			pred[i] = sum[i];
+	}
 }
 
 // NARROW: the caller knows every candidate of the stream is MODE 0 (see fa_narrow_only)

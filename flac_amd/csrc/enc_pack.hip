@@ -7,7 +7,7 @@
 // ---------------------------------------------------------------------------------------------
 // k_pack
 // ---------------------------------------------------------------------------------------------
-#define PK_CAPW 8192  // window of the frame's bitstream held in LDS, in 32-bit words
+#define PK_CAPW 4096  // window of the frame's bitstream held in LDS, in 32-bit words
 
 __constant__ uint16_t c_crc16_table[256];
 __constant__ uint16_t c_crc16_pow[32];  // x^(8 * 2^j) mod the CRC-16 polynomial
@@ -215,7 +215,7 @@ __device__ __forceinline__ void drain(PkShared &S, uint32_t *slot, uint32_t slot
 }
 
 template <int HIST, bool NARROW>
-__global__ __launch_bounds__(FA_THREADS) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
                                                      const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag)
 {
 	__shared__ PkShared S;

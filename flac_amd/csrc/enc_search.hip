@@ -62,7 +62,7 @@ __device__ __forceinline__ void accumulate_chunk(const int32_t (&res)[FA_CHUNK],
 // inside the frame and inside one partition and its sum fits 32 bits; warm-up samples (index <
 // order, the first thread or two) are taken back out afterwards.
 __device__ __forceinline__ void accumulate_biased(const uint32_t (&db)[FA_CHUNK], const int32_t (&pred)[FA_CHUNK], uint64_t *gs, uint32_t base,
-                                                  uint32_t order, uint32_t bsf, uint32_t psize, bool quick, uint32_t bias)
+                                                  uint32_t order, uint32_t bsf, uint32_t psize, bool quick, uint32_t bias, uint32_t quick_part)
 {
 	if (quick) {
 		uint32_t t32 = 0;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void accumulate_biased(const uint32_t (&db)[FA_CHUNK]
 				if (base + i < order)
 					t32 -= abs32((int32_t)((db[i] - (uint32_t)pred[i]) ^ bias));
 		}
-		atomicAdd((unsigned long long *)&gs[base / psize], (unsigned long long)t32);
+		atomicAdd((unsigned long long *)&gs[quick_part], (unsigned long long)t32);
 	} else {
 		int32_t res[FA_CHUNK];
 #pragma unroll
@@ -121,7 +121,7 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 }
 
 #ifndef SEARCH_WAVES
-#define SEARCH_WAVES 3
+#define SEARCH_WAVES 4
 #endif
 
 template <int HIST, bool NARROW>
@@ -389,6 +389,9 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			for (int i = 0; i < FA_CHUNK; i++)
 				db[i] = (uint32_t)d[HIST + i] ^ bias;
 			const bool chunk_inside = base + FA_CHUNK <= bsf;
+			// the chunk's finest partition, recomputed only when a candidate's partition size differs
+			// from the one before (the size is the same in every lane)
+			uint32_t part_psize = 0, part_of_chunk = 0;
 			// the next candidate's parameters and coefficients are fetched from LDS while the current
 			// one is computed; at the loop top they move to scalar registers
 			if (HIST >= 12 && sbps <= 16) {
@@ -425,8 +428,12 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					}
 					int32_t pred[FA_CHUNK];
 					lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
+					if (psize != part_psize) {
+						part_psize = psize;
+						part_of_chunk = base / psize;
+					}
 					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
-					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias);
+					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
 				}
 			} else {
 				uint32_t nxp[4];
@@ -459,8 +466,12 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					}
 					int32_t pred[FA_CHUNK];
 					lpc_pred16_any<HIST, NARROW>(d, qs, order, shift, mode, pred);
+					if (psize != part_psize) {
+						part_psize = psize;
+						part_of_chunk = base / psize;
+					}
 					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
-					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias);
+					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
 				}
 			}
 		}
