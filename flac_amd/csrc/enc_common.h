@@ -157,7 +157,8 @@ __device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *p
 // LDS stores later, so that other work can be placed between them.
 template <int HIST>
 __device__ __forceinline__ void stage_load(int32_t (&v)[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS], const void *pcm, uint32_t channels,
-                                           uint32_t sample_bytes, uint32_t pairs, uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t tile_base)
+                                           uint32_t sample_bytes, uint32_t pairs, uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t tile_base,
+                                           uint32_t tid = threadIdx.x)
 {
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void stage_load(int32_t (&v)[(ST_HP(HIST) + FA_TILE +
 	uint64_t wide[NIT];
 #pragma unroll
 	for (uint32_t i = 0; i < NIT; i++) {
-		const uint32_t j = threadIdx.x + i * FA_THREADS;
+		const uint32_t j = tid + i * FA_THREADS;
 		int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
 		idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
 		wide[i] = frame_start + (uint32_t)idx;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void stage_load(int32_t (&v)[(ST_HP(HIST) + FA_TILE +
 
 template <int HIST>
 __device__ __forceinline__ void stage_store(int32_t *lds, const int32_t (&v)[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS], uint32_t bsf,
-                                            uint32_t wasted, uint32_t tile_base)
+                                            uint32_t wasted, uint32_t tile_base, uint32_t tid = threadIdx.x)
 {
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
@@ -185,7 +186,7 @@ __device__ __forceinline__ void stage_store(int32_t *lds, const int32_t (&v)[(ST
 	const uint32_t n = HP + ((tile_len + 15) & ~15u);
 #pragma unroll
 	for (uint32_t i = 0; i < NIT; i++) {
-		const uint32_t j = threadIdx.x + i * FA_THREADS;
+		const uint32_t j = tid + i * FA_THREADS;
 		const int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
 		const bool inside = idx >= 0 && (uint32_t)idx < bsf;
 		if (j < n)
@@ -195,11 +196,21 @@ __device__ __forceinline__ void stage_store(int32_t *lds, const int32_t (&v)[(ST
 
 template <int HIST>
 __device__ __forceinline__ void stage_tile(int32_t *lds, const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs,
-                                           uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t wasted, uint32_t tile_base)
+                                           uint64_t frame_start, uint32_t bsf, uint32_t s, uint32_t wasted, uint32_t tile_base,
+                                           uint32_t tid = threadIdx.x)
 {
 	int32_t v[(ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS];
-	stage_load<HIST>(v, pcm, channels, sample_bytes, pairs, frame_start, bsf, s, tile_base);
-	stage_store<HIST>(lds, v, bsf, wasted, tile_base);
+	stage_load<HIST>(v, pcm, channels, sample_bytes, pairs, frame_start, bsf, s, tile_base, tid);
+	stage_store<HIST>(lds, v, bsf, wasted, tile_base, tid);
+}
+
+// The thread index as a value the optimiser cannot relate to threadIdx.x: address arithmetic built
+// on it is not shared with (and kept alive for) distant code that does the same sums.
+__device__ __forceinline__ uint32_t opaque_tid()
+{
+	uint32_t t = threadIdx.x;
+	asm volatile("" : "+v"(t));
+	return t;
 }
 
 // d[k] = sample (16 t - HIST + k) of the staged tile, k = 0 .. HIST + 15

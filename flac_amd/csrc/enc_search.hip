@@ -364,7 +364,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		for (uint32_t tile = 0; tile < ntiles; tile++) {
 			if (!(tile == 0 && staged)) {
 				__syncthreads();
-				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, wasted, tile * FA_TILE);
+				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
 			}
 			__syncthreads();
 			staged = false;
