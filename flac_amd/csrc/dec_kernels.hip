@@ -170,7 +170,29 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 	const uint64_t p0 = ((uint64_t)blockIdx.x * SYNC_THREADS + tid) * SYNC_BYTES_PER_THREAD;
 	FaFrameCand found[2];  // more than two real headers in 16 bytes cannot happen
 	uint32_t n = 0;
+	// the thread's 16 bytes and the one after them, as five words; only positions that hold the
+	// two sync bytes are looked at further
+	uint32_t w[SYNC_BYTES_PER_THREAD / 4 + 1];
+	{
+		const uint32_t *dw = (const uint32_t *)d;
+		const uint64_t nwords = (P.flac_bytes + 3) / 4;
+#pragma unroll
+		for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4 + 1; k++) {
+			const uint64_t idx = p0 / 4 + k;
+			w[k] = idx < nwords ? dw[idx] : 0u;
+		}
+	}
+	uint32_t hits = 0;
+#pragma unroll
 	for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
+		const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff;
+		const uint32_t b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
+		if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
+			hits |= 1u << i;
+	}
+	while (hits) {
+		const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
+		hits &= hits - 1;
 		const uint64_t p = p0 + i;
 		if (p >= P.flac_bytes)
 			break;

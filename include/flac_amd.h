@@ -146,7 +146,8 @@ void flacamd_decoder_destroy(flacamd_decoder *d);
 /* replaces frame_sync_ + read_frame_ (stream_decoder.c:1941,1996) for a batch of streams whose
  * bytes are resident in device memory.  Output: interleaved PCM, out_sample_bytes wide (2 or 4),
  * at each stream's sample_offset.  frames_out / status per frame are kept on the device and
- * summarised by flacamd_decoder_result. */
+ * summarised by flacamd_decoder_result.  flac_dev must be 4-byte aligned; the buffer is read in
+ * 32-bit words, so the word that holds its last byte is read whole (the extra bytes are ignored). */
 int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_dev, uint64_t flac_bytes,
                            const flacamd_stream_desc *streams_host, uint32_t nstreams,
                            void *pcm_out_dev, uint32_t out_sample_bytes, uint64_t out_capacity_wide,
