@@ -31,12 +31,57 @@ __constant__ int8_t c_fixed_q[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}
 __constant__ uint8_t c_dec_crc8[256];
 __constant__ uint16_t c_dec_crc16[256];
 __constant__ uint16_t c_dec_pow16[32];
+__constant__ uint16_t c_dec_crc16x4[4][256];  // table k: CRC-16 of a byte followed by k zero bytes
+// k_dec_crc works in segments of 64 runs of 8 << c words; lane l's run is followed by 63 - l more
+// runs, so its CRC is multiplied by c_dec_runpow[c][l] = x^(8 * 4 * (8 << c) * (63 - l)); a whole
+// segment further on multiplies by c_dec_segpow[c]
+__constant__ uint16_t c_dec_runpow[4][64];
+__constant__ uint16_t c_dec_segpow[4];
 
 void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
 {
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16), t16, 512);
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_pow16), pow16, 64);
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc8), t8, 256);
+	static uint16_t x4[4][256];
+	for (int e = 0; e < 256; e++) {
+		uint32_t t = t16[e];
+		x4[0][e] = (uint16_t)t;
+		for (int k = 1; k < 4; k++) {
+			t = ((t << 8) & 0xffff) ^ t16[t >> 8];
+			x4[k][e] = (uint16_t)t;
+		}
+	}
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16x4), x4, sizeof(x4));
+	// powers of x modulo x^16 + x^15 + x^2 + 1
+	auto mul = [](uint32_t a, uint32_t b) {
+		uint32_t r = 0;
+		for (int i = 0; i < 16; i++) {
+			if (b & 1)
+				r ^= a;
+			b >>= 1;
+			a <<= 1;
+			if (a & 0x10000)
+				a ^= 0x18005;
+		}
+		return r;
+	};
+	auto xpow8 = [&](uint64_t nbytes) {
+		uint32_t r = 1;
+		for (int j = 0; nbytes; j++, nbytes >>= 1)
+			if (nbytes & 1)
+				r = mul(r, pow16[j]);
+		return r;
+	};
+	static uint16_t runpow[4][64], segpow[4];
+	for (int c = 0; c < 4; c++) {
+		const uint64_t run_bytes = 4ull * (8u << c);
+		for (int l = 0; l < 64; l++)
+			runpow[c][l] = (uint16_t)xpow8(run_bytes * (uint64_t)(63 - l));
+		segpow[c] = (uint16_t)xpow8(run_bytes * 64);
+	}
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_runpow), runpow, sizeof(runpow));
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_segpow), segpow, sizeof(segpow));
 }
 
 __device__ __forceinline__ int find_stream(const FaStream *streams, uint32_t n, uint64_t p)
@@ -790,43 +835,84 @@ __device__ __forceinline__ uint32_t dgf16_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
-__global__ __launch_bounds__(256) void k_dec_crc(const uint8_t *d, FaFrameCand *cands, const uint32_t *ncand_ptr)
+#define CRC_SEG_WORDS 4096  // 64 lanes x 64 words: the largest segment
+
+// One wave per frame.  The frame is cut into segments of 64 equal runs, the first segment padded
+// with zeros IN FRONT (leading zeros do not change a CRC that starts at 0), so every run length and
+// every distance to the end of a segment is one of a few fixed sizes whose powers of x come from
+// tables.  A segment is brought into LDS with coalesced word loads; each lane takes its run through
+// four byte tables at once (table k: the CRC of a byte followed by k zero bytes) and multiplies the
+// result by x^(8 * bytes that follow in the segment); the 64 products are XORed together (the CRC is
+// linear), and segments are chained by crc(A || B) = crc(A) * x^(8 |B|) + crc(B).
+__global__ __launch_bounds__(64) void k_dec_crc(const uint8_t *d, FaFrameCand *cands, const uint32_t *ncand_ptr)
 {
-	__shared__ uint32_t crcs[256];
-	__shared__ uint16_t table[256];
-	const uint32_t tid = threadIdx.x;
-	table[tid] = c_dec_crc16[tid];
+	__shared__ uint32_t seg[CRC_SEG_WORDS];
+	__shared__ uint16_t table[4][256];
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t e = lane; e < 4 * 256 / 2; e += 64)
+		((uint32_t *)&table[0][0])[e] = ((const uint32_t *)&c_dec_crc16x4[0][0])[e];
+	const uint32_t *dw = (const uint32_t *)d;
 	for (uint32_t f = blockIdx.x; f < ncand_ptr[0]; f += gridDim.x) {
-		__syncthreads();
 		const FaFrameCand cd = cands[f];
 		if (cd.status != 1)
 			continue;
 		const uint32_t nbytes = (uint32_t)(cd.end_byte - cd.pos) - 2;
-		const uint8_t *src = d + cd.pos;
-		const uint32_t R = (nbytes + 255) / 256;
-		uint32_t crc = 0;
-		const int64_t start = (int64_t)nbytes - (int64_t)(256 - tid) * R;
-		for (uint32_t i = 0; i < R; i++) {
-			const int64_t b = start + i;
-			if (b >= 0)
-				crc = ((crc << 8) & 0xffff) ^ table[(crc >> 8) ^ src[b]];
-		}
-		crcs[tid] = crc;
-		__syncthreads();
-		uint32_t m = 1;
-		for (uint32_t jj = 0, n = R; n; jj++, n >>= 1)
-			if (n & 1)
-				m = dgf16_mul(m, c_dec_pow16[jj]);
-		for (uint32_t Lv = 0; Lv < 8; Lv++) {
-			const uint32_t mask = (2u << Lv) - 1;
-			if ((tid & mask) == mask)
-				crcs[tid] = dgf16_mul(crcs[tid - (1u << Lv)], m) ^ crcs[tid];
-			m = dgf16_mul(m, m);
+		// the smallest run size that covers the frame in one segment, else the largest
+		uint32_t c = 0;
+		while (c < 3 && 64u * 4u * (8u << c) < nbytes)
+			c++;
+		const uint32_t run = 8u << c, seg_bytes = 256u * run;
+		const uint32_t nseg = (nbytes + seg_bytes - 1) / seg_bytes;
+		const uint32_t len0 = nbytes - (nseg - 1) * seg_bytes;  // bytes in the first segment
+		const uint32_t my_pow = c_dec_runpow[c][lane], seg_pow = c_dec_segpow[c];
+		uint32_t total = 0;
+		for (uint32_t sg = 0; sg < nseg; sg++) {
+			const uint32_t len = sg == 0 ? len0 : seg_bytes;
+			const uint32_t pad = seg_bytes - len;  // zero bytes in front
+			// LDS word j holds input bytes [src0 + 4 j, +4), src0 = where the segment would start
+			// if it were full
+			const int64_t src0 = (int64_t)cd.pos + (sg == 0 ? 0 : (int64_t)len0 + (int64_t)(sg - 1) * seg_bytes) - (int64_t)pad;
+			const uint32_t sh = (uint32_t)(src0 & 3) * 8;
+			const int64_t w0 = src0 >> 2;
 			__syncthreads();
+			// eight words per lane at a time, all sixteen loads issued before the first is used
+			for (uint32_t j0 = lane; j0 < 64 * run; j0 += 64 * 8) {
+				uint32_t lo[8], hi[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					const uint32_t j = j0 + 64 * u;
+					const int64_t gi = w0 + j;
+					const bool need = 4 * (j + 1) > pad;
+					lo[u] = (need && gi >= 0) ? dw[gi] : 0u;
+					hi[u] = (need && sh) ? dw[gi + 1] : 0u;
+				}
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					const uint32_t j = j0 + 64 * u;
+					uint32_t v = sh ? (lo[u] >> sh) | (hi[u] << (32 - sh)) : lo[u];
+					if (4 * j < pad)
+						v = 4 * (j + 1) > pad ? v & (0xffffffffu << (8 * (pad - 4 * j))) : 0u;
+					seg[j] = v;
+				}
+			}
+			__syncthreads();
+			uint32_t crc = 0;
+			if (4 * (lane + 1) * run > pad) {
+				for (uint32_t i = 0; i < run; i++) {
+					const uint32_t v = seg[lane * run + i];
+					crc = table[3][(v & 0xff) ^ (crc >> 8)] ^ table[2][((v >> 8) & 0xff) ^ (crc & 0xff)] ^ table[1][(v >> 16) & 0xff] ^ table[0][v >> 24];
+				}
+			}
+			uint32_t part = dgf16_mul(crc, my_pow);
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1)
+				part ^= (uint32_t)__shfl_xor((int)part, o, 64);
+			total = dgf16_mul(total, seg_pow) ^ part;
 		}
-		if (tid == 0) {
+		if (lane == 0) {
+			const uint8_t *src = d + cd.pos;
 			const uint32_t want = ((uint32_t)src[nbytes] << 8) | src[nbytes + 1];
-			if (crcs[255] != want)
+			if (total != want)
 				cands[f].status = 3;
 		}
 	}
@@ -977,10 +1063,10 @@ void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStr
 
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)
 {
-	uint32_t blocks = P.max_frames < 8192 ? P.max_frames : 8192;
+	uint32_t blocks = P.max_frames < 2048 ? P.max_frames : 2048;  // one wave each, eight per CU
 	if (blocks == 0)
 		blocks = 1;
-	hipLaunchKernelGGL(k_dec_crc, dim3(blocks), dim3(256), 0, st, flac, cands, ncand);
+	hipLaunchKernelGGL(k_dec_crc, dim3(blocks), dim3(64), 0, st, flac, cands, ncand);
 }
 
 void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
