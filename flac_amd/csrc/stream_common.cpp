@@ -68,6 +68,54 @@ extern const char *const FLAC__ChannelAssignmentString[] = {"INDEPENDENT", "LEFT
 extern const char *const FLAC__FrameNumberTypeString[] = {"FRAME_NUMBER_TYPE_FRAME_NUMBER", "FRAME_NUMBER_TYPE_SAMPLE_NUMBER"};
 extern const char *const FLAC__MetadataTypeString[] = {"STREAMINFO", "PADDING", "APPLICATION", "SEEKTABLE", "VORBIS_COMMENT", "CUESHEET", "PICTURE"};
 
+// format.c:96-120: cue sheet and picture field widths, in bits
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_INDEX_OFFSET_LEN = 64;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_INDEX_NUMBER_LEN = 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_INDEX_RESERVED_LEN = 3 * 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_OFFSET_LEN = 64;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_NUMBER_LEN = 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_ISRC_LEN = 12 * 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_TYPE_LEN = 1;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_PRE_EMPHASIS_LEN = 1;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_RESERVED_LEN = 6 + 13 * 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_TRACK_NUM_INDICES_LEN = 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_MEDIA_CATALOG_NUMBER_LEN = 128 * 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_LEAD_IN_LEN = 64;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_IS_CD_LEN = 1;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_RESERVED_LEN = 7 + 258 * 8;
+extern const unsigned FLAC__STREAM_METADATA_CUESHEET_NUM_TRACKS_LEN = 8;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_TYPE_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_MIME_TYPE_LENGTH_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_DESCRIPTION_LENGTH_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_WIDTH_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_HEIGHT_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_DEPTH_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_COLORS_LEN = 32;
+extern const unsigned FLAC__STREAM_METADATA_PICTURE_DATA_LENGTH_LEN = 32;
+// format.c:187-209: the picture types of the ID3v2 APIC frame
+extern const char *const FLAC__StreamMetadata_Picture_TypeString[] = {
+	"Other",
+	"32x32 pixels 'file icon' (PNG only)",
+	"Other file icon",
+	"Cover (front)",
+	"Cover (back)",
+	"Leaflet page",
+	"Media (e.g. label side of CD)",
+	"Lead artist/lead performer/soloist",
+	"Artist/performer",
+	"Conductor",
+	"Band/Orchestra",
+	"Composer",
+	"Lyricist/text writer",
+	"Recording Location",
+	"During recording",
+	"During performance",
+	"Movie/video screen capture",
+	"A bright coloured fish",
+	"Illustration",
+	"Band/artist logotype",
+	"Publisher/Studio logotype"};
+
 FLAC__bool FLAC__format_sample_rate_is_valid(unsigned sample_rate) { return !(sample_rate == 0 || sample_rate > FLAC__MAX_SAMPLE_RATE); }
 
 FLAC__bool FLAC__format_blocksize_is_subset(unsigned blocksize, unsigned sample_rate)
@@ -123,6 +171,137 @@ unsigned FLAC__format_seektable_sort(FLAC__StreamMetadata_SeekTable *t)
 		t->points[i].frame_samples = 0;
 	}
 	return j;
+}
+
+
+// Length of the UTF-8 sequence at p (at most `avail` bytes are looked at), 0 if it is malformed,
+// overlong, a surrogate or U+FFFE / U+FFFF (format.c:322).
+static unsigned fa_utf8_len(const FLAC__byte *p, size_t avail)
+{
+	auto cont = [&](unsigned i) { return i < avail && (p[i] & 0xC0) == 0x80; };
+	const unsigned b = p[0];
+	if (b < 0x80)
+		return 1;
+	if ((b & 0xE0) == 0xC0 && cont(1))
+		return (b & 0xFE) == 0xC0 ? 0 : 2;
+	if ((b & 0xF0) == 0xE0 && cont(1) && cont(2)) {
+		if (b == 0xE0 && (p[1] & 0xE0) == 0x80)
+			return 0;
+		if (b == 0xED && (p[1] & 0xE0) == 0xA0)
+			return 0;
+		if (b == 0xEF && p[1] == 0xBF && (p[2] & 0xFE) == 0xBE)
+			return 0;
+		return 3;
+	}
+	if ((b & 0xF8) == 0xF0 && cont(1) && cont(2) && cont(3))
+		return (b == 0xF0 && (p[1] & 0xF0) == 0x80) ? 0 : 4;
+	if ((b & 0xFC) == 0xF8 && cont(1) && cont(2) && cont(3) && cont(4))
+		return (b == 0xF8 && (p[1] & 0xF8) == 0x80) ? 0 : 5;
+	if ((b & 0xFE) == 0xFC && cont(1) && cont(2) && cont(3) && cont(4) && cont(5))
+		return (b == 0xFC && (p[1] & 0xFC) == 0x80) ? 0 : 6;
+	return 0;
+}
+
+static bool fa_utf8_run_ok(const FLAC__byte *p, size_t n)
+{
+	size_t i = 0;
+	while (i < n) {
+		const unsigned k = fa_utf8_len(p + i, n - i);
+		if (k == 0)
+			return false;
+		i += k;
+	}
+	return true;
+}
+
+// format.c:363
+FLAC__bool FLAC__format_vorbiscomment_entry_name_is_legal(const char *name)
+{
+	for (; *name; name++)
+		if (*name < 0x20 || *name == 0x3d || *name > 0x7d)
+			return 0;
+	return 1;
+}
+
+// format.c:372; length (unsigned)-1 means NUL-terminated
+FLAC__bool FLAC__format_vorbiscomment_entry_value_is_legal(const FLAC__byte *value, unsigned length)
+{
+	const size_t n = length == (unsigned)(-1) ? strlen((const char *)value) : length;
+	return fa_utf8_run_ok(value, n) ? 1 : 0;
+}
+
+// format.c:396
+FLAC__bool FLAC__format_vorbiscomment_entry_is_legal(const FLAC__byte *entry, unsigned length)
+{
+	unsigned i = 0;
+	for (; i < length && entry[i] != '='; i++)
+		if (entry[i] < 0x20 || entry[i] > 0x7D)
+			return 0;
+	if (i == length)
+		return 0;
+	i++;
+	return fa_utf8_run_ok(entry + i, length - i) ? 1 : 0;
+}
+
+// format.c:422
+FLAC__bool FLAC__format_cuesheet_is_legal(const FLAC__StreamMetadata_CueSheet *cs, FLAC__bool cdda, const char **violation)
+{
+	auto fail = [&](const char *why) {
+		if (violation)
+			*violation = why;
+		return 0;
+	};
+	if (cdda) {
+		if (cs->lead_in < 2 * 44100)
+			return fail("CD-DA cue sheet must have a lead-in length of at least 2 seconds");
+		if (cs->lead_in % 588 != 0)
+			return fail("CD-DA cue sheet lead-in length must be evenly divisible by 588 samples");
+	}
+	if (cs->num_tracks == 0)
+		return fail("cue sheet must have at least one track (the lead-out)");
+	if (cdda && cs->tracks[cs->num_tracks - 1].number != 170)
+		return fail("CD-DA cue sheet must have a lead-out track number 170 (0xAA)");
+	for (unsigned i = 0; i < cs->num_tracks; i++) {
+		const FLAC__StreamMetadata_CueSheet_Track &t = cs->tracks[i];
+		const bool lead_out = i == cs->num_tracks - 1;
+		if (t.number == 0)
+			return fail("cue sheet may not have a track number 0");
+		if (cdda && !((t.number >= 1 && t.number <= 99) || t.number == 170))
+			return fail("CD-DA cue sheet track number must be 1-99 or 170");
+		if (cdda && t.offset % 588 != 0)
+			return fail(lead_out ? "CD-DA cue sheet lead-out offset must be evenly divisible by 588 samples"
+			                     : "CD-DA cue sheet track offset must be evenly divisible by 588 samples");
+		if (!lead_out) {
+			if (t.num_indices == 0)
+				return fail("cue sheet track must have at least one index point");
+			if (t.indices[0].number > 1)
+				return fail("cue sheet track's first index number must be 0 or 1");
+		}
+		for (unsigned j = 0; j < t.num_indices; j++) {
+			if (cdda && t.indices[j].offset % 588 != 0)
+				return fail("CD-DA cue sheet track index offset must be evenly divisible by 588 samples");
+			if (j > 0 && t.indices[j].number != t.indices[j - 1].number + 1)
+				return fail("cue sheet track index numbers must increase by 1");
+		}
+	}
+	return 1;
+}
+
+// format.c:501
+FLAC__bool FLAC__format_picture_is_legal(const FLAC__StreamMetadata_Picture *picture, const char **violation)
+{
+	for (const char *p = picture->mime_type; *p; p++)
+		if (*p < 0x20 || *p > 0x7e) {
+			if (violation)
+				*violation = "MIME type string must contain only printable ASCII characters (0x20-0x7e)";
+			return 0;
+		}
+	if (!fa_utf8_run_ok(picture->description, strlen((const char *)picture->description))) {
+		if (violation)
+			*violation = "description string must be valid UTF-8";
+		return 0;
+	}
+	return 1;
 }
 
 }  // extern "C"
