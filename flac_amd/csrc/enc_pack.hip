@@ -214,17 +214,68 @@ __device__ __forceinline__ void drain(PkShared &S, uint32_t *slot, uint32_t slot
 	}
 }
 
-template <int HIST, bool NARROW>
+// signal sg (left, right, mid, side) of a 16-bit stereo word; sg is the same in every lane
+__device__ __forceinline__ int32_t quad_signal(uint32_t w, uint32_t sg)
+{
+	const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
+	return sg == 0 ? l : sg == 1 ? r : sg == 2 ? ((l + r) >> 1) : (l - r);
+}
+
+// What a stereo frame with mid/side needs of its four plans, fetched at entry before it is known
+// which two of them get written.
+struct PkPlans {
+	uint8_t params[4][FA_MAX_PARTS];
+	int32_t q[4][FA_MAX_ORDER];
+	uint4 head[4];   // bits | type, order, precision, shift | part_order, rice2, wide, - | constant
+	uint2 stat[4];   // wasted, subframe bps
+};
+
+// QUAD: 16-bit stereo held as one 32-bit word per wide sample, mid/side evaluated.  Everything the
+// frame needs from global memory (the words of its first tile, the four plans, the channel
+// assignment) is requested at entry in one go; the tile is staged once, as raw words, and each
+// written signal is formed from it in registers.
+template <int HIST, bool NARROW, bool QUAD>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
                                                      const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag)
 {
 	__shared__ PkShared S;
 	__shared__ PkStage<HIST> T;
+	__shared__ PkPlans PL;
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
 	const uint32_t slot_words = P.slot_bytes / 4;
 	uint32_t *slot = slots + (size_t)f * slot_words;
+	constexpr uint32_t HP = ST_HP(HIST);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	const uint32_t *words = (const uint32_t *)pcm + frame_start;
+
+	uint32_t pre_w[QUAD ? NIT : 1];
+	uint8_t pre_params[4] = {0, 0, 0, 0};
+	int32_t pre_q[4] = {0, 0, 0, 0};
+	uint4 pre_head = {0, 0, 0, 0};
+	uint2 pre_stat = {0, 0};
+	if (QUAD) {
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			int32_t idx = (int32_t)j - (int32_t)HP;
+			idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+			pre_w[i] = words[idx];
+		}
+		const FaPlan *fp = plans + (size_t)f * 4;
+#pragma unroll
+		for (int sg = 0; sg < 4; sg++) {
+			pre_params[sg] = fp[sg].params[tid];
+			if (tid < FA_MAX_ORDER)
+				pre_q[sg] = fp[sg].q[tid];
+		}
+		if (tid < 4) {
+			pre_head = *(const uint4 *)(fp + tid);
+			pre_stat.x = stats[(size_t)f * 4 + tid].wasted;
+			pre_stat.y = stats[(size_t)f * 4 + tid].bps;
+		}
+	}
 	const uint32_t ca = assign[f];
 
 	for (uint32_t w = tid; w < PK_CAPW; w += FA_THREADS)
@@ -234,6 +285,26 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		S.base_word = 0;
 		S.frame_crc = 0;
 		S.error = 0;
+	}
+	if (QUAD) {
+#pragma unroll
+		for (int sg = 0; sg < 4; sg++) {
+			PL.params[sg][tid] = pre_params[sg];
+			if (tid < FA_MAX_ORDER)
+				PL.q[sg][tid] = pre_q[sg];
+		}
+		if (tid < 4) {
+			PL.head[tid] = pre_head;
+			PL.stat[tid] = pre_stat;
+		}
+		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			const bool inside = j >= HP && j - HP < bsf;
+			if (j < n0)
+				T.v[j + (j >> 4)] = inside ? (int32_t)pre_w[i] : 0;
+		}
 	}
 	__syncthreads();
 
@@ -337,14 +408,35 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		else if (ca == 2 && c == 0) sig = P.channels + 1;  // side, right
 		else if (ca == 3) sig = P.channels + c;            // mid, side
 		const FaPlan *pl = plans + (size_t)f * P.nsignals + sig;
-		const FaSubStat st = stats[(size_t)f * P.nsignals + sig];
-		const uint32_t type = pl->type, order = pl->order, sbps = st.bps, wasted = st.wasted;
-		const uint32_t precision = pl->precision, po = pl->part_order, rice2 = pl->rice2, mode = pl->wide;
-		const int shift = pl->shift;
-		S.params[tid] = pl->params[tid];
-		if (tid < FA_MAX_ORDER)
-			S.q[tid] = pl->q[tid];
-		__syncthreads();
+		uint32_t type, order, sbps, wasted, precision, po, rice2, mode;
+		int shift;
+		int32_t constant;
+		if (QUAD) {
+			const uint4 hd = PL.head[sig];
+			const uint2 sw = PL.stat[sig];
+			type = hd.y & 0xff;
+			order = (hd.y >> 8) & 0xff;
+			precision = (hd.y >> 16) & 0xff;
+			shift = (int)(int8_t)(hd.y >> 24);
+			po = hd.z & 0xff;
+			rice2 = (hd.z >> 8) & 0xff;
+			mode = (hd.z >> 16) & 0xff;
+			constant = (int32_t)hd.w;
+			wasted = sw.x;
+			sbps = sw.y;
+		} else {
+			const FaSubStat st = stats[(size_t)f * P.nsignals + sig];
+			type = pl->type; order = pl->order; sbps = st.bps; wasted = st.wasted;
+			precision = pl->precision; po = pl->part_order; rice2 = pl->rice2; mode = pl->wide;
+			shift = pl->shift;
+			constant = pl->constant;
+			S.params[tid] = pl->params[tid];
+			if (tid < FA_MAX_ORDER)
+				S.q[tid] = pl->q[tid];
+			__syncthreads();
+		}
+		const uint8_t *params = QUAD ? PL.params[sig] : S.params;
+		const int32_t *qv = QUAD ? PL.q[sig] : S.q;
 
 		// FLAC__subframe_add_* (stream_encoder_framing.c:366-479): type byte, wasted-bits unary
 		uint32_t typebits;
@@ -363,7 +455,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		pos += 8 + wasted;
 		if (type == FA_SUB_CONSTANT) {
 			if (tid == 0)
-				emit_bits(S, pos, sbps, (uint32_t)pl->constant);
+				emit_bits(S, pos, sbps, (uint32_t)constant);
 			pos += sbps;
 			__syncthreads();
 			bitpos = pos;
@@ -373,7 +465,12 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		if (type != FA_SUB_VERBATIM) {
 			// warm-up samples, LPC parameters, entropy coding method header
 			if (tid < order) {
-				const int32_t smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + tid, sig) >> wasted;
+				int32_t smp;
+				if (QUAD && bsf <= FA_TILE) {
+					const uint32_t j = HP + tid;
+					smp = quad_signal((uint32_t)T.v[j + (j >> 4)], sig) >> wasted;
+				} else
+					smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + tid, sig) >> wasted;
 				emit_bits(S, pos + tid * sbps, sbps, (uint32_t)smp);
 			}
 			pos += order * sbps;
@@ -384,7 +481,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 				}
 				pos += 9;
 				if (tid < order)
-					emit_bits(S, pos + tid * precision, precision, (uint32_t)S.q[tid]);
+					emit_bits(S, pos + tid * precision, precision, (uint32_t)qv[tid]);
 				pos += order * precision;
 			}
 			if (tid == 0) {
@@ -402,8 +499,30 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		// ---- per-sample codes, tile by tile ----
 		uint32_t tile_start_bit = pos;
 		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
-			stage_tile<HIST>(T.v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, sig, wasted, tile * FA_TILE);
-			__syncthreads();
+			if (!QUAD) {
+				stage_tile<HIST>(T.v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, sig, wasted, tile * FA_TILE);
+				__syncthreads();
+			} else if (bsf > FA_TILE) {
+				// more than one tile: each is staged when its turn comes, raw like the first
+				__syncthreads();
+				uint32_t w[NIT];
+#pragma unroll
+				for (uint32_t i = 0; i < NIT; i++) {
+					const uint32_t j = tid + i * FA_THREADS;
+					int32_t idx = (int32_t)(tile * FA_TILE + j) - (int32_t)HP;
+					idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+					w[i] = words[idx];
+				}
+				const uint32_t n = HP + ((umin32(bsf - tile * FA_TILE, FA_TILE) + 15) & ~15u);
+#pragma unroll
+				for (uint32_t i = 0; i < NIT; i++) {
+					const uint32_t j = tid + i * FA_THREADS;
+					const int32_t idx = (int32_t)(tile * FA_TILE + j) - (int32_t)HP;
+					if (j < n)
+						T.v[j + (j >> 4)] = (idx >= 0 && (uint32_t)idx < bsf) ? (int32_t)w[i] : 0;
+				}
+				__syncthreads();
+			}
 			const int32_t base = (int32_t)(tile * FA_TILE + tid * FA_CHUNK);
 			int32_t res[FA_CHUNK];
 			uint32_t nbits = 0;
@@ -411,6 +530,13 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 			if (have) {
 				int32_t d[HIST + FA_CHUNK];
 				load_chunk_lds<HIST>(d, T.v);
+				if (QUAD) {
+					// the staged words become the written signal (mid = (L+R)>>1, side = L-R:
+					// stream_encoder.c:1991-1992), minus its wasted bits
+#pragma unroll
+					for (int k = 0; k < HIST + FA_CHUNK; k++)
+						d[k] = quad_signal((uint32_t)d[k], sig) >> wasted;
+				}
 				if (type == FA_SUB_VERBATIM) {
 #pragma unroll
 					for (int i = 0; i < FA_CHUNK; i++)
@@ -418,7 +544,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 				} else if (type == FA_SUB_FIXED)
 					fixed_residual16<HIST>(d, order, res);
 				else
-					lpc_residual16_any<HIST, NARROW>(d, S.q, order, shift, (int)mode, res);
+					lpc_residual16_any<HIST, NARROW>(d, qv, order, shift, (int)mode, res);
 				uint32_t part = (uint32_t)base / psize;
 				uint32_t next = (part + 1) * psize;
 #pragma unroll
@@ -432,7 +558,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 						if (code_kind == 0)
 							nbits += sbps;
 						else {
-							const uint32_t k = S.params[part];
+							const uint32_t k = params[part];
 							const uint32_t uz = ((uint32_t)res[i] << 1) ^ (uint32_t)(res[i] >> 31);
 							nbits += (uz >> k) + 1 + k;
 							if (idx == first_code_sample || idx == part * psize)
@@ -462,7 +588,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 							emit_bits(S, p, sbps, (uint32_t)res[i]);
 							p += sbps;
 						} else {
-							const uint32_t k = S.params[part];
+							const uint32_t k = params[part];
 							if (idx == first_code_sample || idx == part * psize) {
 								emit_bits(S, p, plen, k);
 								p += plen;
@@ -507,8 +633,13 @@ void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
                     uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st)
 {
 	const dim3 grid(B.nframes), block(FA_THREADS);
-#define PACK_LAUNCH(H, N) hipLaunchKernelGGL((k_pack<H, N>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag)
+#define PACK_LAUNCH(H, N) \
+	do { \
+		if (quad) hipLaunchKernelGGL((k_pack<H, N, true>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); \
+		else hipLaunchKernelGGL((k_pack<H, N, false>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); \
+	} while (0)
 	const bool narrow = fa_narrow_only(P);
+	const bool quad = B.pairs && P.nsignals == 4;
 	switch (fa_hist_class(P)) {
 	case 4: PACK_LAUNCH(4, true); break;
 	case 12: if (narrow) PACK_LAUNCH(12, true); else PACK_LAUNCH(12, false); break;
