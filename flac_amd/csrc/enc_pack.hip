@@ -311,10 +311,21 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 	// ---- frame header: FLAC__frame_add_header (stream_encoder_framing.c:219) ----
 	uint32_t bitpos;
 	{
-		uint8_t h[16];
+		// the header's bytes (at most 16) are collected in two 64-bit words, first byte on top;
+		// everything here is the same in all threads
+		uint64_t hw[2] = {0, 0};
 		uint32_t n = 0;
-		h[n++] = 0xff;
-		h[n++] = 0xf8;
+		auto put = [&](uint32_t byte) {
+			const uint64_t v = (uint64_t)(byte & 0xff) << (56 - 8 * (n & 7));
+			if (n < 8)
+				hw[0] |= v;
+			else
+				hw[1] |= v;
+			n++;
+		};
+		auto get = [&](uint32_t i) { return (uint32_t)((i < 8 ? hw[0] : hw[1]) >> (56 - 8 * (i & 7))) & 0xff; };
+		put(0xff);
+		put(0xf8);
 		uint32_t u, bs_hint = 0, sr_hint = 0;
 		switch (bsf) {
 		case 192: u = 1; break;
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 			else v = 0;
 			break;
 		}
-		h[n++] = (uint8_t)((u << 4) | v);
+		put((uint8_t)((u << 4) | v));
 		const uint32_t chcode = ca == 0 ? P.channels - 1 : 7 + ca;
 		uint32_t bcode;
 		switch (P.bps) {
@@ -363,40 +374,43 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		case 24: bcode = 6; break;
 		default: bcode = 0; break;
 		}
-		h[n++] = (uint8_t)((chcode << 4) | (bcode << 1));
+		put((uint8_t)((chcode << 4) | (bcode << 1)));
 		// FLAC__bitwriter_write_utf8_uint32 (bitwriter.c:784)
 		const uint32_t val = B.first_frame + f;
 		if (val < 0x80)
-			h[n++] = (uint8_t)val;
+			put((uint8_t)val);
 		else {
 			const int cont = val < 0x800 ? 1 : val < 0x10000 ? 2 : val < 0x200000 ? 3 : val < 0x4000000 ? 4 : 5;
 			const uint32_t lead = (0xff00u >> (cont + 1)) & 0xff;  // 0xC0, 0xE0, 0xF0, 0xF8, 0xFC
-			h[n++] = (uint8_t)(lead | (val >> (6 * cont)));
+			put((uint8_t)(lead | (val >> (6 * cont))));
 			for (int i = cont - 1; i >= 0; i--)
-				h[n++] = (uint8_t)(0x80 | ((val >> (6 * i)) & 0x3f));
+				put((uint8_t)(0x80 | ((val >> (6 * i)) & 0x3f)));
 		}
 		if (bs_hint == 6)
-			h[n++] = (uint8_t)(bsf - 1);
+			put((uint8_t)(bsf - 1));
 		else if (bs_hint == 7) {
-			h[n++] = (uint8_t)((bsf - 1) >> 8);
-			h[n++] = (uint8_t)(bsf - 1);
+			put((uint8_t)((bsf - 1) >> 8));
+			put((uint8_t)(bsf - 1));
 		}
 		if (sr_hint == 12)
-			h[n++] = (uint8_t)(P.sample_rate / 1000);
+			put((uint8_t)(P.sample_rate / 1000));
 		else if (sr_hint == 13) {
-			h[n++] = (uint8_t)(P.sample_rate >> 8);
-			h[n++] = (uint8_t)P.sample_rate;
+			put((uint8_t)(P.sample_rate >> 8));
+			put((uint8_t)P.sample_rate);
 		} else if (sr_hint == 14) {
-			h[n++] = (uint8_t)((P.sample_rate / 10) >> 8);
-			h[n++] = (uint8_t)(P.sample_rate / 10);
+			put((uint8_t)((P.sample_rate / 10) >> 8));
+			put((uint8_t)(P.sample_rate / 10));
 		}
 		uint8_t crc = 0;  // FLAC__crc8 (crc.c:124)
 		for (uint32_t i = 0; i < n; i++)
-			crc = c_crc8_table[crc ^ h[i]];
-		h[n++] = crc;
+			crc = c_crc8_table[crc ^ get(i)];
+		put(crc);
 		if (tid == 0)
-			for (uint32_t i = 0; i < n; i++)
-				emit_bits(S, 8 * i, 8, h[i]);
+			for (uint32_t i = 0; i < n; i += 4) {
+				const uint32_t nb = n - i < 4 ? n - i : 4;  // bytes in this word
+				const uint32_t word = (uint32_t)((i < 8 ? hw[0] : hw[1]) >> (i & 4 ? 0 : 32));
+				emit_bits(S, 8 * i, 8 * nb, word >> (32 - 8 * nb));
+			}
 		bitpos = 8 * n;
 	}
 	__syncthreads();
