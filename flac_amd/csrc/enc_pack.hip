@@ -12,12 +12,52 @@
 __constant__ uint16_t c_crc16_table[256];
 __constant__ uint16_t c_crc16_pow[32];  // x^(8 * 2^j) mod the CRC-16 polynomial
 __constant__ uint8_t c_crc8_table[256];
+__constant__ uint16_t c_crc16x4[4][256];    // table k: CRC-16 of a byte followed by k zero bytes
+// window_crc16 works on 256 runs of 1 << c words; thread t's run is followed by 255 - t more
+// runs, so its CRC is multiplied by c_crc16_runpow[c][t] = x^(8 * 4 * (1 << c) * (255 - t))
+#define PK_RUN_CLASSES 5
+__constant__ uint16_t c_crc16_runpow[PK_RUN_CLASSES][FA_THREADS];
 
 void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
 {
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_table), t16, 512);
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_pow), pow16, 64);
 	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc8_table), t8, 256);
+	static uint16_t x4[4][256];
+	for (int e = 0; e < 256; e++) {
+		uint32_t t = t16[e];
+		x4[0][e] = (uint16_t)t;
+		for (int k = 1; k < 4; k++) {
+			t = ((t << 8) & 0xffff) ^ t16[t >> 8];
+			x4[k][e] = (uint16_t)t;
+		}
+	}
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16x4), x4, sizeof(x4));
+	// powers of x modulo x^16 + x^15 + x^2 + 1
+	auto mul = [](uint32_t a, uint32_t b) {
+		uint32_t r = 0;
+		for (int i = 0; i < 16; i++) {
+			if (b & 1)
+				r ^= a;
+			b >>= 1;
+			a <<= 1;
+			if (a & 0x10000)
+				a ^= 0x18005;
+		}
+		return r;
+	};
+	auto xpow8 = [&](uint64_t nbytes) {
+		uint32_t r = 1;
+		for (int j = 0; nbytes; j++, nbytes >>= 1)
+			if (nbytes & 1)
+				r = mul(r, pow16[j]);
+		return r;
+	};
+	static uint16_t runpow[PK_RUN_CLASSES][FA_THREADS];
+	for (int c = 0; c < PK_RUN_CLASSES; c++)
+		for (int t = 0; t < FA_THREADS; t++)
+			runpow[c][t] = (uint16_t)xpow8(4ull * (1u << c) * (uint64_t)(FA_THREADS - 1 - t));
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_runpow), runpow, sizeof(runpow));
 }
 
 // product of two polynomials modulo x^16 + x^15 + x^2 + 1
@@ -49,8 +89,8 @@ __device__ __forceinline__ uint32_t gf16_xpow8(uint32_t n)
 struct PkShared {
 	uint32_t W[PK_CAPW];
 	uint32_t scan[4];
-	uint32_t crcs[FA_THREADS];
-	uint16_t crc_table[256];
+	uint32_t crcs[4];
+	uint16_t crc_tables[4][256];
 	uint32_t base_word;
 	uint32_t frame_crc;
 	uint32_t error;
@@ -103,59 +143,48 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(PkShared &S, uint32_t v
 	return off + inc - v;
 }
 
-// a * m modulo the polynomial, for a multiplier that is the same in every lane: the lane's own
-// operand is only bit-tested, the shifting and reducing of m runs on the scalar unit
-__device__ __forceinline__ uint32_t gf16_mul_by(uint32_t a, uint32_t m_uniform)
-{
-	uint32_t r = 0, m = m_uniform;
-#pragma unroll
-	for (int i = 0; i < 16; i++) {
-		r ^= (0u - ((a >> i) & 1u)) & m;
-		m <<= 1;
-		if (m & 0x10000)
-			m ^= 0x18005;
-	}
-	return r;
-}
-
-// CRC-16 of nbytes bytes that start at window word 0 (FLAC__crc16, crc.c:134): each thread takes an
-// equal run of bytes, the runs are right-aligned (leading virtual zeros do not change a CRC that
-// starts at 0), and a tree folds them with multiplications by powers of x: six levels inside each
-// wave by lane shuffles, the four wave results by Horner's rule.  nbytes is the same in all threads.
+// CRC-16 of nbytes (<= 4 PK_CAPW) bytes that start at window word 0 (FLAC__crc16, crc.c:134).  The
+// bytes are taken as 256 runs of 1, 2, 4, 8 or 16 words, padded with zeros IN FRONT (leading zeros do
+// not change a CRC that starts at 0) so that the last run ends with the last byte.  Each thread puts
+// its run through four byte tables at once and multiplies the result by x^(8 * bytes that follow
+// it), a power that comes from a table because the run sizes are fixed; the CRC being linear, the
+// XOR of the 256 products is the answer.  nbytes is the same in all threads.
 __device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
 {
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint32_t R = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nbytes + FA_THREADS - 1) / FA_THREADS));
+	const uint32_t nw = (nbytes + 3) / 4;       // words after padding in front
+	const uint32_t pad = nw * 4 - nbytes;       // 0..3 zero bytes in front
+	uint32_t c = 0;
+	while (c + 1 < PK_RUN_CLASSES && ((uint32_t)FA_THREADS << c) < nw)
+		c++;
+	const uint32_t run = 1u << c;
+	const uint32_t my_pow = c_crc16_runpow[c][tid];
+	// padded word j = stream bytes [4 j - pad, 4 j - pad + 4); the window holds stream bytes
+	// big-endian, four to a word
+	const int32_t first = (int32_t)(tid * run) - (int32_t)(FA_THREADS * run - nw);
 	uint32_t crc = 0;
-	if (R) {
-		const int32_t start = (int32_t)nbytes - (int32_t)((FA_THREADS - tid) * R);
-		for (uint32_t i = 0; i < R; i++) {
-			const int32_t b = start + (int32_t)i;
-			if (b >= 0) {
-				const uint32_t byte = (S.W[b >> 2] >> (24 - 8 * (b & 3))) & 0xff;
-				crc = ((crc << 8) & 0xffff) ^ S.crc_table[(crc >> 8) ^ byte];
-			}
+	if (first + (int32_t)run > 0) {
+		uint32_t prev = first > 0 ? S.W[first - 1] : 0u;
+		for (uint32_t i = 0; i < run; i++) {
+			const int32_t j = first + (int32_t)i;
+			if (j < 0)
+				continue;
+			const uint32_t cur = S.W[j];
+			const uint32_t v = pad ? (prev << (32 - 8 * pad)) | (cur >> (8 * pad)) : cur;
+			prev = cur;
+			crc = S.crc_tables[3][(v >> 24) ^ (crc >> 8)] ^ S.crc_tables[2][((v >> 16) & 0xff) ^ (crc & 0xff)] ^ S.crc_tables[1][(v >> 8) & 0xff] ^
+			      S.crc_tables[0][v & 0xff];
 		}
 	}
-	uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)gf16_xpow8(R));
+	uint32_t part = gf16_mul(crc, my_pow);
 #pragma unroll
-	for (uint32_t L = 0; L < 6; L++) {
-		const uint32_t mask = (2u << L) - 1;
-		const uint32_t below = __shfl_up(crc, 1u << L, 64);
-		const uint32_t folded = gf16_mul_by(below, m) ^ crc;
-		if ((lane & mask) == mask)
-			crc = folded;
-		m = (uint32_t)__builtin_amdgcn_readfirstlane((int)gf16_mul(m, m));
-	}
+	for (int o = 32; o > 0; o >>= 1)
+		part ^= (uint32_t)__shfl_xor((int)part, o, 64);
 	__syncthreads();
-	if (lane == 63)
-		S.crcs[wv] = crc;
+	if (lane == 0)
+		S.crcs[wv] = part;
 	__syncthreads();
-	// m is now x^(8 * 64 R): one wave's worth of bytes
-	uint32_t out = S.crcs[0];
-#pragma unroll
-	for (uint32_t w = 1; w < FA_THREADS / 64; w++)
-		out = gf16_mul_by(out, m) ^ S.crcs[w];
+	const uint32_t out = S.crcs[0] ^ S.crcs[1] ^ S.crcs[2] ^ S.crcs[3];
 	__syncthreads();
 	return out;
 }
@@ -280,7 +309,8 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
 	for (uint32_t w = tid; w < PK_CAPW; w += FA_THREADS)
 		S.W[w] = 0;
-	S.crc_table[tid] = c_crc16_table[tid];
+	for (uint32_t e = tid; e < 4 * 256 / 2; e += FA_THREADS)
+		((uint32_t *)&S.crc_tables[0][0])[e] = ((const uint32_t *)&c_crc16x4[0][0])[e];
 	if (tid == 0) {
 		S.base_word = 0;
 		S.frame_crc = 0;
