@@ -42,17 +42,17 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 	int32_t first;
 	uint32_t orv = 0, ne = 0;
 	{
-		uint64_t wide[NIT + 1];
+		uint32_t wide[NIT + 1];
 		int32_t v[NIT + 1];
 #pragma unroll
 		for (uint32_t i = 0; i < NIT; i++) {
 			const uint32_t j = tid + i * FA_THREADS;
 			int32_t idx = (int32_t)j - (int32_t)HP;
 			idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
-			wide[i] = frame_start + (uint32_t)idx;
+			wide[i] = (uint32_t)idx;
 		}
-		wide[NIT] = frame_start;
-		load_signal_block<(int)NIT + 1>(v, pcm, acc, wide);
+		wide[NIT] = 0;
+		load_signal_block<(int)NIT + 1>(v, pcm, acc, frame_start, wide);
 		first = v[NIT];
 		const uint32_t n0 = HP + ((umin32(bsf, FA_TILE) + 15) & ~15u);
 #pragma unroll

@@ -103,47 +103,53 @@ __device__ __forceinline__ SigAccess sig_access(uint32_t channels, uint32_t samp
 
 __device__ __forceinline__ int32_t sig_combine(uint32_t kind, int32_t x, int32_t y) { return kind == 0 ? x : kind == 1 ? ((x + y) >> 1) : (x - y); }
 
-// v[i] = signal value of wide sample wide[i], for N samples; one branch on the format, none per sample
+// v[i] = signal value of wide sample frame_start + rel[i], for N samples; one branch on the format,
+// none per sample.  The frame's base address is the same in every lane and the per-sample offsets
+// are 32-bit, so each load needs one address register.
 template <int N>
-__device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *pcm, const SigAccess &a, const uint64_t (&wide)[N])
+__device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *pcm, const SigAccess &a, uint64_t frame_start, const uint32_t (&rel)[N])
 {
 	if (a.fmt == 0) {
+		const uint32_t *base = (const uint32_t *)pcm + frame_start;
 		uint32_t w[N];
 #pragma unroll
 		for (int i = 0; i < N; i++)
-			w[i] = ((const uint32_t *)pcm)[wide[i]];
+			w[i] = base[rel[i]];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
 			const int32_t l = (int32_t)(int16_t)(w[i] & 0xffff), r = (int32_t)w[i] >> 16;
 			v[i] = a.kind == 0 ? (a.ca ? r : l) : a.kind == 1 ? ((l + r) >> 1) : (l - r);
 		}
 	} else if (a.fmt == 2) {
+		const int16_t *base = (const int16_t *)pcm + frame_start * a.channels;
 		int32_t x[N], y[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			x[i] = ((const int16_t *)pcm)[wide[i] * a.channels + a.ca];
-			y[i] = ((const int16_t *)pcm)[wide[i] * a.channels + a.cb];
+			x[i] = base[rel[i] * a.channels + a.ca];
+			y[i] = base[rel[i] * a.channels + a.cb];
 		}
 #pragma unroll
 		for (int i = 0; i < N; i++)
 			v[i] = sig_combine(a.kind, x[i], y[i]);
 	} else if (a.fmt == 4) {
+		const int32_t *base = (const int32_t *)pcm + frame_start * a.channels;
 		int32_t x[N], y[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			x[i] = ((const int32_t *)pcm)[wide[i] * a.channels + a.ca];
-			y[i] = ((const int32_t *)pcm)[wide[i] * a.channels + a.cb];
+			x[i] = base[rel[i] * a.channels + a.ca];
+			y[i] = base[rel[i] * a.channels + a.cb];
 		}
 #pragma unroll
 		for (int i = 0; i < N; i++)
 			v[i] = sig_combine(a.kind, x[i], y[i]);
 	} else {
+		const uint8_t *base = (const uint8_t *)pcm + frame_start * a.channels * 3;
 		uint32_t x0[N], x1[N], y0[N], y1[N];
 		int32_t x2[N], y2[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			const uint8_t *px = (const uint8_t *)pcm + (wide[i] * a.channels + a.ca) * 3;
-			const uint8_t *py = (const uint8_t *)pcm + (wide[i] * a.channels + a.cb) * 3;
+			const uint8_t *px = base + (rel[i] * a.channels + a.ca) * 3;
+			const uint8_t *py = base + (rel[i] * a.channels + a.cb) * 3;
 			x0[i] = px[0]; x1[i] = px[1]; x2[i] = (int8_t)px[2];
 			y0[i] = py[0]; y1[i] = py[1]; y2[i] = (int8_t)py[2];
 		}
@@ -163,15 +169,15 @@ __device__ __forceinline__ void stage_load(int32_t (&v)[(ST_HP(HIST) + FA_TILE +
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
 	const SigAccess a = sig_access(channels, sample_bytes, pairs, s);
-	uint64_t wide[NIT];
+	uint32_t rel[NIT];
 #pragma unroll
 	for (uint32_t i = 0; i < NIT; i++) {
 		const uint32_t j = tid + i * FA_THREADS;
 		int32_t idx = (int32_t)(tile_base + j) - (int32_t)HP;
 		idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
-		wide[i] = frame_start + (uint32_t)idx;
+		rel[i] = (uint32_t)idx;
 	}
-	load_signal_block<(int)NIT>(v, pcm, a, wide);
+	load_signal_block<(int)NIT>(v, pcm, a, frame_start, rel);
 }
 
 template <int HIST>

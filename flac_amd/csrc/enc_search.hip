@@ -124,7 +124,9 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 #define SEARCH_WAVES 4
 #endif
 
-template <int HIST, bool NARROW>
+// PAIRS: the PCM is 16-bit stereo read as one 32-bit word per wide sample (a compile-time fact
+// here, so that the other sample formats' code does not weigh on register allocation)
+template <int HIST, bool NARROW, bool PAIRS>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SEARCH_WAVES, SEARCH_WAVES)))
 void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans,
               uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps)
@@ -171,7 +173,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 	for (uint32_t k = 0; k < SR_PRE_COEFS / FA_THREADS; k++)
 		pre_q[k] = (tid + k * FA_THREADS < npre_coefs) ? my_coefs[tid + k * FA_THREADS] : 0;
 	int32_t tile_v[NIT];
-	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, 0);
+	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, 0);
 	const FaSubStat st = stats[task];
 	const uint32_t sbps = st.bps, wasted = st.wasted;
 	const uint32_t hdr = 8 + wasted;
@@ -364,7 +366,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		for (uint32_t tile = 0; tile < ntiles; tile++) {
 			if (!(tile == 0 && staged)) {
 				__syncthreads();
-				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
+				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
 			}
 			__syncthreads();
 			staged = false;
@@ -636,7 +638,11 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 	const SrLayout L = sr_layout(sum_bytes, stage_bytes, alias, ncmax, qstride, P.ncand < SR_PRE_CANDS ? P.ncand : SR_PRE_CANDS,
 	                             ncoef < SR_PRE_COEFS ? ncoef : SR_PRE_COEFS);
 	const size_t lds = L.total;
-#define SEARCH_LAUNCH(H, N) hipLaunchKernelGGL((k_search<H, N>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps)
+#define SEARCH_LAUNCH(H, N) \
+	do { \
+		if (B.pairs) hipLaunchKernelGGL((k_search<H, N, true>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps); \
+		else hipLaunchKernelGGL((k_search<H, N, false>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps); \
+	} while (0)
 	const bool narrow = fa_narrow_only(P);
 #ifdef EXP_ONLY12
 	SEARCH_LAUNCH(12, true);
