@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=SECONDS, help="stream length per GPU (default: the 600 s workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-stream-api", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -221,6 +222,23 @@ def main():
         except Exception as exc:  # the encode line must still be printed
             result["decode"] = {"error": str(exc)}
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    # the gfx950 note prescribes, + WRITE_SIZE); collected by separate runs of this same command
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as f:
+            tr = json.load(f)
+        if dominant in tr.get("kernels", {}):
+            result["roofline"]["traffic"] = tr["kernels"][dominant]["bytes_per_launch"]
+            result["roofline"]["traffic_source"] = tr.get("source")
+    except (OSError, ValueError):
+        pass
+
+    if rank == 0 and world == 1 and not args.no_stream_api:
+        try:
+            result["end_to_end"] = bench_stream_api(flac_amd, pcm32)
+        except Exception as exc:
+            result["end_to_end"] = {"error": str(exc)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline()
         # the same bounded sample through the GPU path: output bytes vs the CPU run
@@ -240,6 +258,44 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_stream_api(flac_amd, pcm32):
+    """The same stream through the libFLAC-compatible API from host memory: int32 samples in,
+    MD5, PCIe both ways, write callbacks.  Never the headline value."""
+    import ctypes as C
+    lib = flac_amd.lib()
+    wide, ch = pcm32.shape
+    data = np.ascontiguousarray(pcm32, dtype=np.int32)
+    WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint, C.c_uint, C.c_void_p)
+    got = [0]
+
+    def on_write(_e, _buf, nbytes, _samples, _frame, _c):
+        got[0] += nbytes
+        return 0
+    cb = WRITE_CB(on_write)
+    lib.FLAC__stream_encoder_new.restype = C.c_void_p
+    enc = C.c_void_p(lib.FLAC__stream_encoder_new())
+    for name, v in (("channels", ch), ("bits_per_sample", BPS), ("sample_rate", RATE), ("compression_level", LEVEL)):
+        getattr(lib, "FLAC__stream_encoder_set_" + name)(enc, C.c_uint(v))
+    lib.FLAC__stream_encoder_set_total_samples_estimate(enc, C.c_uint64(wide))
+    t0 = time.perf_counter()
+    st = lib.FLAC__stream_encoder_init_stream(enc, cb, None, None, None, None)
+    if st != 0:
+        raise RuntimeError("init_stream status %d" % st)
+    t1 = time.perf_counter()
+    chunk = 1 << 20
+    for pos in range(0, wide, chunk):
+        n = min(chunk, wide - pos)
+        if not lib.FLAC__stream_encoder_process_interleaved(enc, data[pos:pos + n].ctypes.data_as(C.c_void_p), C.c_uint(n)):
+            raise RuntimeError("process_interleaved failed")
+    if not lib.FLAC__stream_encoder_finish(enc):
+        raise RuntimeError("finish failed")
+    t2 = time.perf_counter()
+    lib.FLAC__stream_encoder_delete(enc)
+    return {"value": wide * ch / (t2 - t1) / 1e6, "unit": "MSamples/s", "seconds": t2 - t1, "init_seconds": t1 - t0, "bytes": got[0],
+            "what": "FLAC__stream_encoder_process_interleaved of the same 600 s stream from host int32: MD5, host<->device copies and "
+                    "write callbacks included; one host thread"}
 
 
 def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev):

@@ -89,6 +89,7 @@ struct flacamd_encoder {
 	uint32_t *errflag;    // [0] device error bits, [1] loose mid/side state out
 	// staging for the host-buffer entry point
 	int32_t *stage_pcm;
+	int16_t *stage_host16;  // pinned: samples narrowed to 16 bits before they cross PCIe
 	uint8_t *stage_out;
 	size_t stage_out_bytes;
 	int profiling;
@@ -129,6 +130,7 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 	(void)hipFree(e->offsets);
 	(void)hipFree(e->errflag);
 	(void)hipFree(e->stage_pcm);
+	(void)hipHostFree(e->stage_host16);
 	(void)hipFree(e->stage_out);
 	for (int i = 0; i <= FLACAMD_ENC_STAGES; i++)
 		if (e->ev[i])
@@ -387,9 +389,22 @@ extern "C" int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm
 	}
 	if (wide_samples > (uint64_t)e->max_frames * P.blocksize)
 		return fa_fail(FLACAMD_E_INVALID, "batch larger than the encoder's capacity");
-	HIP_TRY(hipMemcpy(e->stage_pcm, pcm, sizeof(int32_t) * wide_samples * P.channels, hipMemcpyHostToDevice));
+	// Streams of up to 16 bits cross PCIe as int16 (half the bytes), which also puts stereo on the
+	// kernels' one-word-per-wide-sample paths; the results do not depend on the container width.
+	uint32_t container = 4;
+	if (P.bps <= 16) {
+		const size_t n = (size_t)wide_samples * P.channels;
+		if (!e->stage_host16 &&
+		    hipHostMalloc((void **)&e->stage_host16, sizeof(int16_t) * (size_t)e->max_frames * P.blocksize * P.channels, hipHostMallocDefault) != hipSuccess)
+			return fa_fail(FLACAMD_E_NOMEM, "pinned staging buffer: hipHostMalloc failed");
+		for (size_t i = 0; i < n; i++)
+			e->stage_host16[i] = (int16_t)pcm[i];
+		HIP_TRY(hipMemcpy(e->stage_pcm, e->stage_host16, sizeof(int16_t) * n, hipMemcpyHostToDevice));
+		container = 2;
+	} else
+		HIP_TRY(hipMemcpy(e->stage_pcm, pcm, sizeof(int32_t) * wide_samples * P.channels, hipMemcpyHostToDevice));
 	uint32_t nf = 0;
-	int rc = flacamd_encode_frames(e, e->stage_pcm, 4, wide_samples, first_frame, is_last, loose_state, e->stage_out, e->stage_out_bytes,
+	int rc = flacamd_encode_frames(e, e->stage_pcm, container, wide_samples, first_frame, is_last, loose_state, e->stage_out, e->stage_out_bytes,
 	                               nullptr, nullptr, &nf, nullptr);
 	if (rc)
 		return rc;

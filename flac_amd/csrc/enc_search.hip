@@ -126,10 +126,13 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 
 // PAIRS: the PCM is 16-bit stereo read as one 32-bit word per wide sample (a compile-time fact
 // here, so that the other sample formats' code does not weigh on register allocation)
-template <int HIST, bool NARROW, bool PAIRS>
+// DOT2: every signal this launch covers fits 16 bits, so the two-taps-per-instruction residual is
+// the only one compiled in; otherwise only the tap-at-a-time one is.  A launch covers the signals
+// listed in sig_list (four bits each, nsel of them) of every frame.
+template <int HIST, bool NARROW, bool PAIRS, bool DOT2>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SEARCH_WAVES, SEARCH_WAVES)))
 void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans,
-              uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps)
+              uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps, unsigned long long sig_list, uint32_t nsel)
 {
 // debugging aid: the first time thread 0 passes point k, the shader clock goes to stamps[block][k]
 #define STAMP(k) do { if (stamps && threadIdx.x == 0 && first_pass) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -154,8 +157,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 	FaLpcCand *lcand = (FaLpcCand *)(smem + L.lcand);   // candidate slots fetched at entry
 	int32_t *allq = (int32_t *)(smem + L.allq);         // coefficients fetched at entry
 
-	const uint32_t task = blockIdx.x;
-	const uint32_t f = task / P.nsignals, s = task % P.nsignals;
+	const uint32_t f = blockIdx.x / nsel, s = (uint32_t)(sig_list >> (4 * (blockIdx.x % nsel))) & 15u;
+	const uint32_t task = f * P.nsignals + s;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
@@ -396,7 +399,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			uint32_t part_psize = 0, part_of_chunk = 0;
 			// the next candidate's parameters and coefficients are fetched from LDS while the current
 			// one is computed; at the loop top they move to scalar registers
-			if (HIST >= 12 && sbps <= 16) {
+			if (DOT2) {
 				// samples and coefficients fit 16 bits: two taps per instruction
 				int32_t Pk[HIST + FA_CHUNK - 1];
 #pragma unroll
@@ -480,6 +483,10 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		STAMP(5);
 		__syncthreads();
 		STAMP(6);
+		{
+		// what follows works from a fresh copy of the thread index, so that nothing derived from it
+		// earlier is kept alive (spilled) across the residual loop
+		const uint32_t tid = opaque_tid();
 
 		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): every finest sum, truncated to
 		// 32 bits where the reference's accumulator is that narrow (:3803-3833), is added into the
@@ -583,6 +590,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			}
 		}
 		__syncthreads();
+		}
 		STAMP(8);
 		first_pass = false;
 	}
@@ -623,7 +631,7 @@ static uint32_t search_sum_bytes(const FaEncParams &P, uint32_t ncmax)
 void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
                       const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st)
 {
-	const dim3 grid(B.nframes * P.nsignals), block(FA_THREADS);
+	const dim3 block(FA_THREADS);
 	const int hist = fa_hist_class(P);
 	uint32_t ncmax = 5 + P.ncand;
 	if (ncmax > SR_MAXGROUP)
@@ -638,20 +646,36 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 	const SrLayout L = sr_layout(sum_bytes, stage_bytes, alias, ncmax, qstride, P.ncand < SR_PRE_CANDS ? P.ncand : SR_PRE_CANDS,
 	                             ncoef < SR_PRE_COEFS ? ncoef : SR_PRE_COEFS);
 	const size_t lds = L.total;
+	// signals that fit 16 bits go to the launch with the two-taps-per-instruction residual: all of
+	// them below 16 bits per sample, all but the side signal (one bit wider) at 16
+	unsigned long long list_dot2 = 0, list_taps = 0;
+	uint32_t n_dot2 = 0, n_taps = 0;
+	for (uint32_t sg = 0; sg < P.nsignals; sg++) {
+		const uint32_t width = P.bps + ((P.do_ms && sg == P.channels + 1) ? 1u : 0u);
+		if (hist >= 12 && width <= 16)
+			list_dot2 |= (unsigned long long)sg << (4 * n_dot2++);
+		else
+			list_taps |= (unsigned long long)sg << (4 * n_taps++);
+	}
+#define SEARCH_LAUNCH1(H, N, PR, D, LIST, NSEL) \
+	hipLaunchKernelGGL((k_search<H, N, PR, D>), dim3(B.nframes * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
+	                   stamps, LIST, NSEL)
 #define SEARCH_LAUNCH(H, N) \
 	do { \
-		if (B.pairs) hipLaunchKernelGGL((k_search<H, N, true>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps); \
-		else hipLaunchKernelGGL((k_search<H, N, false>), grid, block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, stamps); \
+		if (B.pairs) { \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, true, (H >= 12), list_dot2, n_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, true, false, list_taps, n_taps); \
+		} else { \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, false, (H >= 12), list_dot2, n_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, false, false, list_taps, n_taps); \
+		} \
 	} while (0)
 	const bool narrow = fa_narrow_only(P);
-#ifdef EXP_ONLY12
-	SEARCH_LAUNCH(12, true);
-#else
 	switch (hist) {
 	case 4: SEARCH_LAUNCH(4, true); break;
 	case 12: if (narrow) SEARCH_LAUNCH(12, true); else SEARCH_LAUNCH(12, false); break;
 	default: if (narrow) SEARCH_LAUNCH(32, true); else SEARCH_LAUNCH(32, false); break;
 	}
-#endif
+#undef SEARCH_LAUNCH1
 #undef SEARCH_LAUNCH
 }
