@@ -12,6 +12,8 @@
 
 #include "flac_amd.h"
 #include "md5.h"
+
+#include <thread>
 #include "stream_common.h"
 
 extern "C" {
@@ -238,8 +240,18 @@ bool encode_and_emit(FLAC__StreamEncoder *e, size_t wide, bool is_last)
 	q->frame_bytes->resize(nfr_max);
 	uint32_t nf = 0;
 	size_t total = 0;
+	// The MD5 of these samples (FLAC__MD5Accumulate, process_frame_ stream_encoder.c:2870) is serial
+	// host work; it runs on a helper thread while the GPU codes the same samples.  Every sample
+	// passes here exactly once and in order, so the digest is the one the reference computes.
+	std::thread md5_helper;
+	if (p->do_md5)
+		md5_helper = std::thread([q, pcm, wide, ch, p]() {
+			fa_md5_accumulate_interleaved(&q->md5, pcm, wide * ch, (p->bits_per_sample + 7) / 8);
+		});
 	int rc = flacamd_encode_frames_host(q->dev, pcm, wide, q->current_frame_number, is_last ? 1 : 0, &q->loose_state, q->out->data(),
 	                                    q->out->size(), q->frame_bytes->data(), &nf, &total);
+	if (md5_helper.joinable())
+		md5_helper.join();
 	if (rc != FLACAMD_OK) {
 		p->state = rc == FLACAMD_E_NOMEM ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
 		return false;
@@ -323,11 +335,6 @@ bool drain_ring(FLAC__StreamEncoder *e, bool force)
 	}
 }
 
-void append_md5(FLAC__StreamEncoder *e, const int32_t *interleaved, size_t wide)
-{
-	if (e->protected_->do_md5)
-		fa_md5_accumulate_interleaved(&e->private_->md5, interleaved, wide * e->protected_->channels, (e->protected_->bits_per_sample + 7) / 8);
-}
 
 // update_metadata_ (stream_encoder.c:2516): patch STREAMINFO and the seek table in place
 void update_metadata(FLAC__StreamEncoder *e)
@@ -784,7 +791,6 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 		const unsigned n = (unsigned)((samples - done) < room ? (samples - done) : room);
 		q->ring->resize((q->buffered + n) * ch);
 		memcpy(q->ring->data() + q->buffered * ch, buffer + (size_t)done * ch, sizeof(int32_t) * (size_t)n * ch);
-		append_md5(e, buffer + (size_t)done * ch, n);
 		q->buffered += n;
 		done += n;
 		if (!drain_ring(e, false))
