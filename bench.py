@@ -151,7 +151,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    enc.status()
+    if not os.environ.get("FLAC_AMD_BENCH_NOCHECK"):  # kernel experiments whose output is knowingly wrong
+        enc.status()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -10,7 +10,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflac_amd.so")
+# FLAC_AMD_LIB: load another build of the library (kernel experiments)
+LIB_PATH = os.environ.get("FLAC_AMD_LIB") or os.path.join(_HERE, "lib", "libflac_amd.so")
 
 MAX_APOD = 32
 ENC_STAGES = 8

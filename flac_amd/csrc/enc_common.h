@@ -264,6 +264,25 @@ __device__ __forceinline__ uint32_t rice_bits_estimate(uint32_t k, uint32_t n, u
 	return 4u + (1u + k) * n + (k ? (uint32_t)(sum >> (k - 1)) : (uint32_t)(sum << 1)) - (n >> 1);
 }
 
+// the same two for sums known to fit 32 bits
+__device__ __forceinline__ uint32_t rice_k_from_sum32(uint32_t sum, uint32_t n, uint32_t limit)
+{
+	uint32_t k = 0;
+	if (sum > n) {
+		k = ilog2u(sum) - ilog2u(n);
+		if ((n << k) < sum)
+			k++;
+	}
+	if (k >= limit)
+		k = limit - 1;
+	return k;
+}
+
+__device__ __forceinline__ uint32_t rice_bits_estimate32(uint32_t k, uint32_t n, uint32_t sum)
+{
+	return 4u + (1u + k) * n + (k ? (sum >> (k - 1)) : (sum << 1)) - (n >> 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // residual arithmetic: d[HIST + i] is sample i of the thread's chunk; res[i] for its 16 samples
 // ---------------------------------------------------------------------------------------------

@@ -120,6 +120,9 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 	return L;
 }
 
+#ifndef FA_EXP
+#define FA_EXP 0
+#endif
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 4
 #endif
@@ -366,7 +369,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		STAMP(3);
 
 		// ---- residuals of every candidate of the group, tile by tile, all in registers ----
-		for (uint32_t tile = 0; tile < ntiles; tile++) {
+		for (uint32_t tile = 0; tile < ((FA_EXP == 5 || FA_EXP == 8) ? 0u : ntiles); tile++) {
 			if (!(tile == 0 && staged)) {
 				__syncthreads();
 				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
@@ -432,13 +435,27 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 							nxq[k] = cqp[(g + 1) * NQP + k];
 					}
 					int32_t pred[FA_CHUNK];
+#if FA_EXP == 4
+#pragma unroll
+					for (int i = 0; i < FA_CHUNK; i++) pred[i] = Pk[HIST + i - 2] >> shift;
+#else
 					lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
+#endif
 					if (psize != part_psize) {
 						part_psize = psize;
 						part_of_chunk = base / psize;
 					}
+#if FA_EXP == 3
+					{
+						uint32_t t = 0;
+#pragma unroll
+						for (int i = 0; i < FA_CHUNK; i++) t ^= (uint32_t)pred[i];
+						atomicAdd((unsigned long long *)&sums[(size_t)g * 2 * PF + part_of_chunk], (unsigned long long)t);
+					}
+#else
 					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
 					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
+#endif
 				}
 			} else {
 				uint32_t nxp[4];
@@ -488,11 +505,68 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		// earlier is kept alive (spilled) across the residual loop
 		const uint32_t tid = opaque_tid();
 
+		const uint32_t fpo = frame_max_po;
+		if (PF <= 64) {
+			// ---- precompute_partition_info_sums_ (stream_encoder.c:3774) and set_partitioned_rice_
+			// (stream_encoder.c:3943) with a wave per candidate: lane l holds finest sum l, a butterfly
+			// of lane exchanges gives every lane the sum of its enclosing partition at each coarser
+			// level; lane l then prices the finest partition l and one coarser one (the lanes whose
+			// index has t trailing zeros share out the partitions t + 1 levels up), so nothing waits
+			// on LDS between the levels. ----
+			const uint32_t wv = tid >> 6, ln = tid & 63;
+			const uint32_t tz = ln ? (uint32_t)__builtin_ctz(ln) : 0u;
+			for (uint32_t g = wv; g < ng; g += FA_THREADS / 64) {
+				const uint4 q = *(const uint4 *)(gq + 4 * g);
+				const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
+				uint64_t *gs = sums + (size_t)g * 2 * PF;
+				const bool mine = ln < (1u << pm);
+				uint64_t v[7];
+				v[0] = mine ? gs[ln] : 0ull;
+				if (q.x >> 16) {
+					// the reference's accumulator is 32 bits wide here (stream_encoder.c:3803-3833)
+					v[0] &= 0xffffffffull;
+					if (mine)
+						gs[ln] = v[0];
+				}
+#pragma unroll
+				for (int j = 0; j < 6; j++)
+					v[j + 1] = v[j] + (uint64_t)__shfl_xor((unsigned long long)v[j], 1 << j, 64);
+				// the coarser partition this lane prices: level pm - 1 - tz, the one enclosing lane ln
+				uint64_t sc = v[1];
+#pragma unroll
+				for (int j = 1; j < 6; j++)
+					sc = tz == (uint32_t)j ? v[j + 1] : sc;
+				const int lc = (int)pm - 1 - (int)tz;
+				const bool have_c = mine && ln != 0 && lc >= (int)pmn;
+				const uint32_t poc = have_c ? (uint32_t)lc : 0u;
+				const uint32_t pc = ln >> (tz + 1);
+				const uint32_t nf = (bsf >> pm) - (ln == 0 ? q.y : 0u);
+				const uint32_t nc = (bsf >> poc) - (pc == 0 ? q.y : 0u);
+				const bool narrow = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v[6] >> 32)) == 0;
+				uint32_t bf, bc;
+				if (narrow) {
+					const uint32_t kf = (pm == 0) ? q.z : rice_k_from_sum32((uint32_t)v[0], nf, P.rice_limit);
+					const uint32_t kc = (poc == 0) ? q.z : rice_k_from_sum32((uint32_t)sc, nc, P.rice_limit);
+					bf = rice_bits_estimate32(kf, nf, (uint32_t)v[0]);
+					bc = rice_bits_estimate32(kc, nc, (uint32_t)sc);
+				} else {
+					const uint32_t kf = (pm == 0) ? q.z : rice_k_from_sum(v[0], nf, P.rice_limit);
+					const uint32_t kc = (poc == 0) ? q.z : rice_k_from_sum(sc, nc, P.rice_limit);
+					bf = rice_bits_estimate(kf, nf, v[0]);
+					bc = rice_bits_estimate(kc, nc, sc);
+				}
+				if (mine)
+					atomicAdd(&pbits[g * 16 + pm], bf);
+				if (have_c) {
+					atomicAdd(&pbits[g * 16 + poc], bc);
+					gs[(2u << pm) - (2u << poc) + pc] = sc;   // the winner's parameters are derived from these
+				}
+			}
+		} else {
 		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): every finest sum, truncated to
 		// 32 bits where the reference's accumulator is that narrow (:3803-3833), is added into the
 		// partition above it at each coarser level.  The adds are LDS atomics nobody waits for. ----
-		const uint32_t fpo = frame_max_po;
-		for (uint32_t e = tid; e < (ng << fpo); e += FA_THREADS) {
+		for (uint32_t e = tid; e < ((FA_EXP == 2 || FA_EXP == 7 || FA_EXP == 8) ? 0u : (ng << fpo)); e += FA_THREADS) {
 			const uint32_t g = e >> fpo, part = e & (PF - 1);
 			const uint4 q = *(const uint4 *)(gq + 4 * g);
 			const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
@@ -509,7 +583,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		}
 		__syncthreads();
 		// ---- set_partitioned_rice_ (stream_encoder.c:3943) for every (candidate, order, partition) ----
-		for (uint32_t e = tid; e < (ng << (fpo + 1)); e += FA_THREADS) {
+		for (uint32_t e = tid; e < ((FA_EXP == 1 || FA_EXP == 7 || FA_EXP == 8) ? 0u : (ng << (fpo + 1))); e += FA_THREADS) {
 			const uint32_t g = e >> (fpo + 1), idx = e & (2 * PF - 1);
 			const uint4 q = *(const uint4 *)(gq + 4 * g);
 			const uint64_t sm = sums[(size_t)g * 2 * PF + idx];
@@ -527,6 +601,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					atomicAdd(&pbits[g * 16 + po], rice_bits_estimate(k, n, sm));
 				}
 			}
+		}
 		}
 		__syncthreads();
 		STAMP(7);
