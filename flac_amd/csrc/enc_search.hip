@@ -120,9 +120,6 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 	return L;
 }
 
-#ifndef FA_EXP
-#define FA_EXP 0
-#endif
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 4
 #endif
@@ -369,7 +366,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		STAMP(3);
 
 		// ---- residuals of every candidate of the group, tile by tile, all in registers ----
-		for (uint32_t tile = 0; tile < ((FA_EXP == 5 || FA_EXP == 8) ? 0u : ntiles); tile++) {
+		for (uint32_t tile = 0; tile < ntiles; tile++) {
 			if (!(tile == 0 && staged)) {
 				__syncthreads();
 				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
@@ -435,27 +432,13 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 							nxq[k] = cqp[(g + 1) * NQP + k];
 					}
 					int32_t pred[FA_CHUNK];
-#if FA_EXP == 4
-#pragma unroll
-					for (int i = 0; i < FA_CHUNK; i++) pred[i] = Pk[HIST + i - 2] >> shift;
-#else
 					lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
-#endif
 					if (psize != part_psize) {
 						part_psize = psize;
 						part_of_chunk = base / psize;
 					}
-#if FA_EXP == 3
-					{
-						uint32_t t = 0;
-#pragma unroll
-						for (int i = 0; i < FA_CHUNK; i++) t ^= (uint32_t)pred[i];
-						atomicAdd((unsigned long long *)&sums[(size_t)g * 2 * PF + part_of_chunk], (unsigned long long)t);
-					}
-#else
 					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
 					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
-#endif
 				}
 			} else {
 				uint32_t nxp[4];
@@ -566,7 +549,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): every finest sum, truncated to
 		// 32 bits where the reference's accumulator is that narrow (:3803-3833), is added into the
 		// partition above it at each coarser level.  The adds are LDS atomics nobody waits for. ----
-		for (uint32_t e = tid; e < ((FA_EXP == 2 || FA_EXP == 7 || FA_EXP == 8) ? 0u : (ng << fpo)); e += FA_THREADS) {
+		for (uint32_t e = tid; e < (ng << fpo); e += FA_THREADS) {
 			const uint32_t g = e >> fpo, part = e & (PF - 1);
 			const uint4 q = *(const uint4 *)(gq + 4 * g);
 			const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
@@ -583,7 +566,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		}
 		__syncthreads();
 		// ---- set_partitioned_rice_ (stream_encoder.c:3943) for every (candidate, order, partition) ----
-		for (uint32_t e = tid; e < ((FA_EXP == 1 || FA_EXP == 7 || FA_EXP == 8) ? 0u : (ng << (fpo + 1))); e += FA_THREADS) {
+		for (uint32_t e = tid; e < (ng << (fpo + 1)); e += FA_THREADS) {
 			const uint32_t g = e >> (fpo + 1), idx = e & (2 * PF - 1);
 			const uint4 q = *(const uint4 *)(gq + 4 * g);
 			const uint64_t sm = sums[(size_t)g * 2 * PF + idx];
