@@ -234,3 +234,48 @@ class Decoder:
         ms = (C.c_float * DEC_STAGES)()
         _check(lib().flacamd_decoder_stage_ms(self._h, ms))
         return {lib().flacamd_decoder_stage_name(i).decode(): float(ms[i]) for i in range(DEC_STAGES)}
+
+
+# ---------------------------------------------------------------------------------------------
+# PCM containers (include/flac_amd_pcm.h)
+# ---------------------------------------------------------------------------------------------
+PCM_RAW, PCM_WAVE, PCM_RF64, PCM_WAVE64, PCM_AIFF, PCM_AIFF_C = range(6)
+
+
+class PcmFormat(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "container", "channels", "sample_rate", "bits_per_sample", "shift", "is_big_endian", "is_unsigned",
+        "channel_mask", "bytes_per_wide_sample", "reserved")] + [
+        ("data_offset", C.c_uint64), ("data_bytes", C.c_uint64), ("total_wide_samples", C.c_uint64)]
+
+
+def pcm_parse_header(data, channel_map_none=False):
+    """flacamd_pcm_parse_header on the first bytes of a WAVE / RF64 / Wave64 / AIFF / AIFF-C file."""
+    fmt = PcmFormat()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    _check(lib().flacamd_pcm_parse_header(buf, C.c_size_t(len(data)), int(bool(channel_map_none)), C.byref(fmt)))
+    return fmt
+
+
+def pcm_write_header(container, channels, bits_per_sample, sample_rate, channel_mask, wide_samples):
+    """flacamd_pcm_write_header: the header bytes of a file that holds wide_samples samples."""
+    n = C.c_size_t(0)
+    _check(lib().flacamd_pcm_write_header(container, channels, bits_per_sample, sample_rate, channel_mask,
+                                          C.c_uint64(wide_samples), None, C.c_size_t(0), C.byref(n)))
+    out = (C.c_uint8 * n.value)()
+    _check(lib().flacamd_pcm_write_header(container, channels, bits_per_sample, sample_rate, channel_mask,
+                                          C.c_uint64(wide_samples), out, C.c_size_t(n.value), C.byref(n)))
+    return bytes(out)
+
+
+def pcm_unpack(src_ptr, fmt, wide_samples, dst_ptr, dst_sample_bytes, flag_ptr, stream=0):
+    """flacamd_pcm_unpack on device pointers (integers)."""
+    _check(lib().flacamd_pcm_unpack(C.c_void_p(src_ptr), C.byref(fmt), C.c_uint64(wide_samples), C.c_void_p(dst_ptr),
+                                    C.c_uint32(dst_sample_bytes), C.c_void_p(flag_ptr), C.c_void_p(stream)))
+
+
+def pcm_pack(src_ptr, src_sample_bytes, channels, bits_per_sample, container, wide_samples, dst_ptr, stream=0):
+    """flacamd_pcm_pack on device pointers (integers)."""
+    _check(lib().flacamd_pcm_pack(C.c_void_p(src_ptr), C.c_uint32(src_sample_bytes), C.c_uint32(channels),
+                                  C.c_uint32(bits_per_sample), C.c_uint32(container), C.c_uint64(wide_samples),
+                                  C.c_void_p(dst_ptr), C.c_void_p(stream)))
