@@ -330,17 +330,20 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 struct BitRd {
 	const uint32_t *wg;  // the frame's first word in global memory (word index wbase of the input)
 	uint64_t wbase;      // index of that word in the input
-	uint64_t buf;        // window, left-aligned: bit 63 is the bit at bpos
+	uint64_t buf;        // window, left-aligned: bit 63 is the next unread bit
 	uint32_t avail;      // valid bits in buf; 33..64 after br_refill
 	uint32_t nxt;        // the word that follows the window (already byte-swapped)
 	uint32_t wrel;       // index, relative to wbase, of the word after nxt
 	uint32_t nrel;       // words from wbase to the end of the input (saturated)
 	uint32_t limit;      // words [0, limit) have been in the ring; the last RING_WORDS of them still are
-	uint32_t bpos;       // bits consumed, counted from the start of word wbase
 	uint32_t bend;       // first bit past the stream on the same scale (saturated)
 	const uint32_t *ring;  // this lane's RING_WORDS words of LDS
 	bool err;
 };
+
+// Bits consumed, counted from the start of word wbase: the window and the word after it are words
+// [.., wrel) of the frame, of which `avail` + 32 bits are still unread.
+__device__ __forceinline__ uint32_t br_pos(const BitRd &r) { return 32u * (r.wrel - 1u) - r.avail; }
 
 // The refill protocol keeps limit - RING_WORDS <= wrel, so one compare tells whether the ring has
 // the word; a lane that has outrun its ring reads global memory itself.
@@ -348,23 +351,22 @@ __device__ __forceinline__ uint32_t br_fetch(BitRd &r)
 {
 	uint32_t v;
 	if (r.wrel < r.limit)
-		v = r.ring[r.wrel & (RING_WORDS - 1)];
+		v = r.ring[r.wrel & (RING_WORDS - 1)];   // the ring holds the words already byte-swapped
 	else
-		v = r.wrel < r.nrel ? r.wg[r.wrel] : 0u;
+		v = __builtin_bswap32(r.wrel < r.nrel ? r.wg[r.wrel] : 0u);
 	r.wrel++;
-	return __builtin_bswap32(v);
+	return v;
 }
 
 // start reading at bit sbit (< 32 * RING_CHUNK - 96) of the frame's first chunk
 __device__ __forceinline__ void br_start(BitRd &r, uint32_t sbit)
 {
 	r.err = false;
-	r.bpos = sbit;
 	const uint32_t i = sbit >> 5, s = sbit & 31;
-	const uint64_t two = ((uint64_t)__builtin_bswap32(r.ring[i]) << 32) | __builtin_bswap32(r.ring[i + 1]);
+	const uint64_t two = ((uint64_t)r.ring[i] << 32) | r.ring[i + 1];
 	r.buf = two << s;
 	r.avail = 64 - s;
-	r.nxt = __builtin_bswap32(r.ring[i + 2]);
+	r.nxt = r.ring[i + 2];
 	r.wrel = i + 3;
 }
 
@@ -383,7 +385,6 @@ __device__ __forceinline__ void br_drop(BitRd &r, uint32_t n)
 {
 	r.buf <<= n;
 	r.avail -= n;
-	r.bpos += n;
 }
 
 __device__ __forceinline__ uint32_t br_get(BitRd &r, uint32_t n)
@@ -418,7 +419,7 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 		}
 		n += 32;
 		br_drop(r, 32);
-		if (r.bpos > r.bend) {
+		if (br_pos(r) > r.bend) {
 			r.err = true;
 			return n;
 		}
@@ -462,7 +463,7 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 #pragma unroll
 	for (int sl = 0; sl < 2; sl++) {
 		if (pm.lane[sl] >= 0) {
-			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = pm.data[sl];
+			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = __builtin_bswap32(pm.data[sl]);
 			if ((int)tid == pm.lane[sl])
 				r.limit += RING_CHUNK;
 			pm.lane[sl] = -1;
@@ -517,7 +518,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		hist[j] = 0;
 	}
 	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
-	uint32_t k = 0, kmask = 0, raw_bits = 0;
+	uint32_t k = 0, kp1 = 1, raw_bits = 0;
 	bool escape = false;
 	// samples below seg_end are plain Rice symbols with parameter k; fast_end is seg_end while
 	// the ring is sure to hold every word the rest of the block can ask for, else 0
@@ -529,7 +530,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * DEC_MAXLW];
 	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
 		pump_service(pm, r, L, tid, live, nwords);
-		if (r.bpos > r.bend) {
+		if (br_pos(r) > r.bend) {
 			r.err = true;
 			work_end = 0;
 			seg_end = 0;
@@ -541,18 +542,21 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			const uint32_t i = i0 + s;
 			// the word a refill at the end of this sample would take
 			const uint32_t ring_word = r.ring[r.wrel & (RING_WORDS - 1)];
-			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the window
+			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the top 32 bits of
+			// the window (which always holds at least 33): count of leading zeros (64 stands for
+			// "none of the 32 is set", which fails the length test), stop bit, k low bits
 			const uint32_t hi = (uint32_t)(r.buf >> 32);
-			const uint32_t z = (uint32_t)__builtin_clz(hi | (hi == 0));  // unused when hi is 0
-			const uint32_t total = z + 1 + k;
-			const bool fast = i < fast_end && hi != 0 && total <= r.avail;
-			const uint32_t lsbs = (uint32_t)(r.buf >> ((64 - total) & 63)) & kmask;
+			uint32_t z;
+			asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(hi));
+			z = z < 64u ? z : 64u;
+			const uint32_t total = z + kp1;
+			const bool fast = i < fast_end && total <= 32;
+			const uint32_t lsbs = __builtin_amdgcn_ubfe(hi, 32u - total, k);
 			const uint32_t uf = (z << k) | lsbs;
 			int32_t res = fast ? (int32_t)((uf >> 1) ^ (0u - (uf & 1))) : h.constant;
 			const uint32_t used = fast ? total : 0;
 			r.buf <<= used;
 			r.avail -= used;
-			r.bpos += used;
 			if (!fast && i < work_end) {
 				if (h.kind >= 2) {
 					if (i < h.order)
@@ -570,7 +574,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 								raw_bits = br_get(r, 5);
 								k = 0;
 							}
-							kmask = (1u << k) - 1;
+							kp1 = k + 1;
 							next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
 							seg_end = escape ? 0 : next_part;
 						}
@@ -602,9 +606,24 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
 				} else {
 					int32_t sum = 0;
+					if (MUL24) {
+						// two chains of 24-bit multiply-adds, one instruction per tap
+						int32_t s0, s1 = 0;
+						asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(hist[0]));
+						if (M > 1)
+							asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(hist[1]));
 #pragma unroll
-					for (int j = 0; j < M; j++)
-						sum += MUL24 ? __mul24(q[j], hist[j]) : q[j] * hist[j];
+						for (int j = 2; j < M; j += 2) {
+							asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(q[j]), "v"(hist[j]), "v"(s0));
+							if (j + 1 < M)
+								asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(q[j + 1]), "v"(hist[j + 1]), "v"(s1));
+						}
+						sum = s0 + s1;
+					} else {
+#pragma unroll
+						for (int j = 0; j < M; j++)
+							sum += q[j] * hist[j];
+					}
 					pred = sum >> h.shift;
 				}
 				v = (int32_t)((uint32_t)res + (uint32_t)pred);
@@ -620,7 +639,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				const uint64_t add = (uint64_t)(c ? r.nxt : 0u) << ((32 - r.avail) & 63);
 				r.buf |= add;
 				r.avail += c ? 32u : 0u;
-				r.nxt = c ? __builtin_bswap32(ring_word) : r.nxt;
+				r.nxt = c ? ring_word : r.nxt;
 				r.wrel += c ? 1u : 0u;
 			}
 		}
@@ -680,8 +699,8 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		}
 #pragma unroll
 		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
-			L.ring[ln][tid] = first[2 * ln];
-			L.ring[ln][RING_CHUNK + tid] = first[2 * ln + 1];
+			L.ring[ln][tid] = __builtin_bswap32(first[2 * ln]);
+			L.ring[ln][RING_CHUNK + tid] = __builtin_bswap32(first[2 * ln + 1]);
 		}
 		r.limit = 2 * RING_CHUNK;
 	}
@@ -770,7 +789,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 				if (h.po > 0 && (h.psize < h.order || (h.psize << h.po) != bsf))
 					r.err = true;
 			}
-			if (r.bpos > r.bend)
+			if (br_pos(r) > r.bend)
 				r.err = true;
 		}
 		// ---- samples, dispatched on what the wave as a whole needs ----
@@ -799,16 +818,17 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 #undef DECODE
 	}
 	if (live) {
-		if (r.bpos > r.bend)
+		if (br_pos(r) > r.bend)
 			r.err = true;
 		// read_zero_padding_ (stream_decoder.c:2773): the pad bits must be zero
-		if (!r.err && (r.bpos & 7)) {
-			const uint32_t n = 8 - (r.bpos & 7);
+		if (!r.err && (br_pos(r) & 7)) {
+			const uint32_t n = 8 - (br_pos(r) & 7);
 			if (br_get(r, n) != 0)
 				r.err = true;
 		}
-		const uint64_t end_byte = r.wbase * 4 + (r.bpos >> 3) + 2;
-		const bool past = !endless && ((r.bpos > r.bend) || ((uint64_t)(r.bpos >> 3) + 2) * 8 > r.bend);
+		const uint32_t bpos = br_pos(r);
+		const uint64_t end_byte = r.wbase * 4 + (bpos >> 3) + 2;
+		const bool past = !endless && ((bpos > r.bend) || ((uint64_t)(bpos >> 3) + 2) * 8 > r.bend);
 		if (past)
 			r.err = true;
 		cands[j].end_byte = end_byte;
