@@ -329,11 +329,13 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 		fa_launch_lpc(P, B, e->stats, e->autoc, e->cands, e->coefs, st);
 	STAGE_MARK();
 	// FLAC_AMD_STAMPS: per-workgroup cycle stamps of k_search land in the (by now consumed) autocorrelation buffer
-	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, getenv("FLAC_AMD_STAMPS") ? (unsigned long long *)e->autoc : nullptr, st);
+	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, (getenv("FLAC_AMD_STAMPS") && strcmp(getenv("FLAC_AMD_STAMPS"), "pack")) ? (unsigned long long *)e->autoc : nullptr, st);
 	STAGE_MARK();
 	fa_launch_decide(P, B, e->plans, e->assign, e->errflag + 1, st);
 	STAGE_MARK();
-	fa_launch_pack(P, B, pcm_dev, e->stats, e->plans, e->assign, e->slots, fb, e->errflag, st);
+	// FLAC_AMD_STAMPS=pack: the same for k_pack (the candidate buffer is consumed by then)
+	fa_launch_pack(P, B, pcm_dev, e->stats, e->plans, e->assign, e->slots, fb, e->errflag,
+	               (getenv("FLAC_AMD_STAMPS") && !strcmp(getenv("FLAC_AMD_STAMPS"), "pack")) ? (unsigned long long *)e->autoc : nullptr, st);
 	STAGE_MARK();
 	fa_launch_scan(fb, B.nframes, fo, st);
 	STAGE_MARK();

@@ -16,7 +16,7 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
                       const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st);
 void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st);
 void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
-                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st);
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st);
 void fa_launch_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets, hipStream_t st);
 void fa_launch_compact(const FaEncParams &P, const FaBatch &B, const uint32_t *slots, const uint32_t *frame_bytes, const uint64_t *offsets,
                        uint8_t *out, uint64_t out_capacity, uint32_t *errflag, hipStream_t st);

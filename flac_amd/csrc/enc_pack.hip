@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t gf16_xpow8(uint32_t n)
 }
 
 struct PkShared {
-	uint32_t W[PK_CAPW];
+	uint32_t W[PK_CAPW] __attribute__((aligned(16)));
 	uint32_t scan[4];
 	uint32_t crcs[4];
 	uint16_t crc_tables[4][256];
@@ -192,7 +192,8 @@ __device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
 // Write window words [0, nwords) to the frame slot (big-endian bit order -> byte order), fold
 // their CRC into the frame CRC, slide the window.  keep_partial: word nwords holds the
 // unfinished tail and becomes word 0.
-__device__ __forceinline__ void flush_window(PkShared &S, uint32_t *slot, uint32_t slot_words, uint32_t nwords, bool keep_partial, bool with_crc)
+__device__ __forceinline__ void flush_window(PkShared &S, uint32_t *slot, uint32_t slot_words, uint32_t nwords, bool keep_partial, bool with_crc,
+                                             bool final = false)
 {
 	const uint32_t tid = threadIdx.x;
 	if (with_crc && nwords) {
@@ -208,6 +209,8 @@ __device__ __forceinline__ void flush_window(PkShared &S, uint32_t *slot, uint32
 			S.error = 1;
 	}
 	__syncthreads();
+	if (final)
+		return;  // the window is not used again
 	const uint32_t carry = keep_partial ? S.W[nwords] : 0u;
 	__syncthreads();
 	for (uint32_t w = tid; w < nwords + 2 && w < PK_CAPW; w += FA_THREADS)
@@ -265,8 +268,10 @@ struct PkPlans {
 // written signal is formed from it in registers.
 template <int HIST, bool NARROW, bool QUAD>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
-                                                     const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag)
+                                                     const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps)
 {
+// debugging aid: thread 0's shader clock at point k goes to stamps[block][k]
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 	__shared__ PkShared S;
 	__shared__ PkStage<HIST> T;
 	__shared__ PkPlans PL;
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
 	const uint32_t *words = (const uint32_t *)pcm + frame_start;
+	STAMP(0);
 
 	uint32_t pre_w[QUAD ? NIT : 1];
 	uint8_t pre_params[4] = {0, 0, 0, 0};
@@ -307,8 +313,8 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 	}
 	const uint32_t ca = assign[f];
 
-	for (uint32_t w = tid; w < PK_CAPW; w += FA_THREADS)
-		S.W[w] = 0;
+	for (uint32_t w = tid; w < PK_CAPW / 4; w += FA_THREADS)
+		((uint4 *)S.W)[w] = make_uint4(0, 0, 0, 0);
 	for (uint32_t e = tid; e < 4 * 256 / 2; e += FA_THREADS)
 		((uint32_t *)&S.crc_tables[0][0])[e] = ((const uint32_t *)&c_crc16x4[0][0])[e];
 	if (tid == 0) {
@@ -337,6 +343,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		}
 	}
 	__syncthreads();
+	STAMP(1);
 
 	// ---- frame header: FLAC__frame_add_header (stream_encoder_framing.c:219) ----
 	uint32_t bitpos;
@@ -444,6 +451,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		bitpos = 8 * n;
 	}
 	__syncthreads();
+	STAMP(2);
 
 	// ---- subframes in written order (stream_encoder.c:3091-3151) ----
 	for (uint32_t c = 0; c < P.channels; c++) {
@@ -538,7 +546,9 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 			first_code_sample = order;
 			code_kind = 1;
 		}
-		__syncthreads();
+		if (!QUAD)
+			__syncthreads();  // S.params / S.q of this subframe; with QUAD the plans are in LDS since entry
+		STAMP(3 + 4 * (c & 1));
 
 		// ---- per-sample codes, tile by tile ----
 		uint32_t tile_start_bit = pos;
@@ -611,8 +621,10 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 					}
 				}
 			}
+			STAMP(4 + 4 * (c & 1));
 			uint32_t tile_bits;
 			const uint32_t my_start = tile_start_bit + block_exclusive_scan(S, nbits, &tile_bits);
+			STAMP(5 + 4 * (c & 1));
 			const uint32_t tile_end_bit = tile_start_bit + tile_bits;
 			drain(S, slot, slot_words, tile_end_bit, [&]() {
 				if (!have)
@@ -646,41 +658,46 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 					}
 				}
 			});
+			STAMP(6 + 4 * (c & 1));
 			tile_start_bit = tile_end_bit;
 		}
 		bitpos = tile_start_bit;
 		__syncthreads();
 	}
 
+	STAMP(11);
 	// ---- zero padding, CRC-16 over everything so far (stream_encoder.c:2885-2900), final flush ----
 	const uint32_t nbytes = (bitpos + 7) >> 3;
 	{
 		const uint32_t bw = S.base_word;
 		const uint32_t tail_bytes = nbytes - bw * 4;
 		const uint32_t c = window_crc16(S, tail_bytes);
+		STAMP(12);
 		if (tid == 0) {
 			const uint32_t crc = gf16_mul(S.frame_crc, gf16_xpow8(tail_bytes)) ^ c;
 			emit_bits(S, nbytes * 8, 16, crc);
 		}
 		__syncthreads();
 		const uint32_t total_words = (nbytes + 2 + 3) / 4;
-		flush_window(S, slot, slot_words, total_words - bw, false, false);
+		flush_window(S, slot, slot_words, total_words - bw, false, false, true);
 	}
+	STAMP(13);
 	if (tid == 0) {
 		frame_bytes[f] = nbytes + 2;
 		if (S.error)
 			atomicOr(errflag, 1u);
 	}
+#undef STAMP
 }
 
 void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
-                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, hipStream_t st)
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st)
 {
 	const dim3 grid(B.nframes), block(FA_THREADS);
 #define PACK_LAUNCH(H, N) \
 	do { \
-		if (quad) hipLaunchKernelGGL((k_pack<H, N, true>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); \
-		else hipLaunchKernelGGL((k_pack<H, N, false>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); \
+		if (quad) hipLaunchKernelGGL((k_pack<H, N, true>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps); \
+		else hipLaunchKernelGGL((k_pack<H, N, false>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps); \
 	} while (0)
 	const bool narrow = fa_narrow_only(P);
 	const bool quad = B.pairs && P.nsignals == 4;
