@@ -356,20 +356,22 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 //
 // Tasks (frame, signal, apodization) are taken two at a time: the windowed samples of a task pair
 // sit interleaved in LDS, {a[k], b[k]}, so that one packed multiply and one packed add advance the
-// same lag of both tasks.  A lane owns lags 2g and 2g+1 of its pair and walks the samples two
-// steps per iteration: one 16-byte read for x[i], x[i+1], one for the next two of the sliding
-// x[i+2g ..] window.  Positions past the frame are zero, and adding the resulting +-0 products
-// leaves an accumulator unchanged.
+// same lag of both tasks.  A lane owns ONE lag of its pair (the sums are serial chains, so the
+// number of lanes is all the parallelism there is) and walks the samples two steps per iteration:
+// one 16-byte read for x[i], x[i+1] and one for x[i+l], x[i+l+1].  The first two waves take the even
+// lags, whose second read is aligned as it stands; the other two take the odd lags and carry the
+// first of their two values over from the previous read.  Positions past the frame are zero, and
+// adding the resulting +-0 products leaves an accumulator unchanged.
 //
 // Tiles of AC_T steps are double-buffered: the global loads for the next tile are in flight while
 // the current one is computed.  16-bit stereo with mid/side and a single window (the common case)
 // has a dedicated staging path in which one 32-bit load yields the sample of all four signals of a
 // frame, i.e. of two task pairs.
 // ---------------------------------------------------------------------------------------------
-#define AC_T 64           // steps per tile
+#define AC_T 128          // steps per tile
 #define AC_MAXROWS 36     // task pairs per workgroup at most (even)
 #define AC_FPW 5          // frames per wave in the dedicated staging path: ceil(AC_MAXROWS / 2 / 4)
-#define AC_NK 2           // 64-lane strips per row: AC_T + 2 * ceil(33 / 2) <= 128
+#define AC_NK 3           // 64-lane strips per row: AC_T + 33 + 1 <= 192
 
 typedef float fa_f2 __attribute__((ext_vector_type(2)));
 typedef float fa_f4 __attribute__((ext_vector_type(4)));
@@ -379,14 +381,15 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 {
 	extern __shared__ __attribute__((aligned(16))) float xs[];
 	const uint32_t lag = P.max_lpc_order + 1;
-	const uint32_t row_pairs = AC_T + 2 * G;
+	const uint32_t row_pairs = (AC_T + lag + 1) & ~1u;
 	const uint32_t buf_floats = rows_per_block * row_pairs * 2;
-	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
 	const uint32_t nrows = (ntasks + 1) / 2;
 	const uint32_t row0 = blockIdx.x * rows_per_block;
-	const uint32_t my_j = tid / G, my_g = tid % G;
-	const bool active = my_j < rows_per_block && row0 + my_j < nrows;
+	// G lanes per row in each half of the workgroup: lags 2 g (threads 0..127) and 2 g + 1 (128..255)
+	const uint32_t odd = tid >> 7, my_j = (tid & 127) / G, my_l = 2 * ((tid & 127) % G) + odd;
+	const bool active = my_j < rows_per_block && row0 + my_j < nrows && my_l < lag;
 	const bool quad = B.pairs && P.nsignals == 4 && P.napod == 1;  // rows 2f, 2f+1 = (L,R), (M,S) of frame f
 	const uint32_t ntiles = (P.blocksize + AC_T - 1) / AC_T;
 	const uint32_t frames_pb = rows_per_block / 2, frame0 = row0 / 2;
@@ -413,6 +416,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 #pragma unroll
 		for (uint32_t n = 0; n < AC_FPW; n++) {
 			const uint32_t f = frame0 + wv + 4 * n;
+			if (wv + 4 * n >= frames_pb)
+				continue;
 #pragma unroll
 			for (uint32_t m = 0; m < AC_NK; m++) {
 				const uint32_t idx = c0 + lane + 64 * m;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 		plain_stage(0, xs);
 	__syncthreads();
 
-	fa_f2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
+	fa_f2 acc = {0.0f, 0.0f};
 	for (uint32_t t = 0; t < ntiles; t++) {
 		const float *cur_buf = xs + (t & 1) * buf_floats;
 		float *next_buf = xs + ((t + 1) & 1) * buf_floats;
@@ -487,18 +492,26 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 			quad_load(t + 1);
 		if (active) {
 			const float *row = cur_buf + (size_t)my_j * row_pairs * 2;
-			fa_f4 win = *(const fa_f4 *)(row + 4 * my_g);  // pairs 2g, 2g+1
+			if (!odd) {
 #pragma unroll 4
-			for (uint32_t i = 0; i < AC_T; i += 2) {
-				const fa_f4 a = *(const fa_f4 *)(row + 2 * i);                    // pairs i, i+1
-				const fa_f4 nx = *(const fa_f4 *)(row + 2 * i + 4 * my_g + 4);   // pairs i+2g+2, i+2g+3
-				const fa_f2 a0 = {a.x, a.y}, a1 = {a.z, a.w};
-				const fa_f2 b0 = {win.x, win.y}, b1 = {win.z, win.w}, b2 = {nx.x, nx.y};
-				acc0 = acc0 + a0 * b0;
-				acc1 = acc1 + a0 * b1;
-				acc0 = acc0 + a1 * b1;
-				acc1 = acc1 + a1 * b2;
-				win = nx;
+				for (uint32_t i = 0; i < AC_T; i += 2) {
+					const fa_f4 a = *(const fa_f4 *)(row + 2 * i);             // pairs i, i+1
+					const fa_f4 b = *(const fa_f4 *)(row + 2 * (i + my_l));    // pairs i+l, i+l+1
+					const fa_f2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+					acc = acc + a0 * b0;
+					acc = acc + a1 * b1;
+				}
+			} else {
+				fa_f2 win = *(const fa_f2 *)(row + 2 * my_l);                      // pair l
+#pragma unroll 4
+				for (uint32_t i = 0; i < AC_T; i += 2) {
+					const fa_f4 a = *(const fa_f4 *)(row + 2 * i);                 // pairs i, i+1
+					const fa_f4 b = *(const fa_f4 *)(row + 2 * (i + my_l + 1));    // pairs i+l+1, i+l+2
+					const fa_f2 a0 = {a.x, a.y}, a1 = {a.z, a.w}, b1 = {b.x, b.y};
+					acc = acc + a0 * win;
+					acc = acc + a1 * b1;
+					win = fa_f2{b.z, b.w};
+				}
 			}
 		}
 		if (more) {
@@ -512,17 +525,9 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 	if (active) {
 		const uint32_t task = 2 * (row0 + my_j);
 		float *o = autoc + (size_t)task * (FA_MAX_ORDER + 1);
-		const uint32_t l0 = 2 * my_g, l1 = l0 + 1;
-		if (l0 < lag)
-			o[l0] = acc0.x;
-		if (l1 < lag)
-			o[l1] = acc1.x;
-		if (task + 1 < ntasks) {
-			if (l0 < lag)
-				o[FA_MAX_ORDER + 1 + l0] = acc0.y;
-			if (l1 < lag)
-				o[FA_MAX_ORDER + 1 + l1] = acc1.y;
-		}
+		o[my_l] = acc.x;
+		if (task + 1 < ntasks)
+			o[FA_MAX_ORDER + 1 + my_l] = acc.y;
 	}
 }
 
@@ -841,14 +846,18 @@ void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, co
                      hipStream_t st)
 {
 	const uint32_t lag = P.max_lpc_order + 1;
-	const uint32_t G = (lag + 1) / 2;  // lag pairs per task pair
-	uint32_t rows = FA_THREADS / G;
+	const uint32_t G = (lag + 1) / 2;  // lanes per task pair in each half of a workgroup (even lags, odd lags)
+	uint32_t rows = (FA_THREADS / 2) / G;
 	if (rows > AC_MAXROWS)
 		rows = AC_MAXROWS;
+	// both tile buffers of a workgroup within 48 KiB, so that three workgroups share a compute unit
+	const uint32_t row_bytes = ((AC_T + lag + 1) & ~1u) * 2 * sizeof(float);
+	if (rows > 49152 / (2 * row_bytes))
+		rows = 49152 / (2 * row_bytes);
 	rows &= ~1u;
 	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
 	const uint32_t nrows = (ntasks + 1) / 2;
-	const size_t lds = (size_t)2 * rows * (AC_T + 2 * G) * 2 * sizeof(float);
+	const size_t lds = (size_t)2 * rows * row_bytes;
 	hipLaunchKernelGGL(k_autoc, dim3((nrows + rows - 1) / rows), dim3(FA_THREADS), lds, st, P, B, pcm, stats, windows, autoc, rows, G);
 }
 
