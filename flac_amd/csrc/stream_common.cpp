@@ -325,12 +325,13 @@ int fa_stream_device(void)
 	return env ? atoi(env) : 0;
 }
 
-void fa_serialize_metadata(const FLAC__StreamMetadata *m, std::vector<uint8_t> &out)
+void fa_serialize_metadata(const FLAC__StreamMetadata *m, std::vector<uint8_t> &out, bool own_vendor)
 {
 	Bytes w{out};
-	const uint32_t vlen = (uint32_t)strlen(FLAC__VENDOR_STRING);
+	const uint32_t vlen = own_vendor ? (uint32_t)strlen(FLAC__VENDOR_STRING) : m->data.vorbis_comment.vendor_string.length;
+	const void *vstr = own_vendor ? (const void *)FLAC__VENDOR_STRING : (const void *)m->data.vorbis_comment.vendor_string.entry;
 	uint32_t len = m->length;
-	if (m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT) {
+	if (m->type == FLAC__METADATA_TYPE_VORBIS_COMMENT && own_vendor) {
 		// the library's own vendor string replaces the caller's (framing.c:64-69)
 		len -= m->data.vorbis_comment.vendor_string.length;
 		len += vlen;
@@ -367,7 +368,7 @@ void fa_serialize_metadata(const FLAC__StreamMetadata *m, std::vector<uint8_t> &
 		break;
 	case FLAC__METADATA_TYPE_VORBIS_COMMENT:
 		w.le32(vlen);
-		w.raw(FLAC__VENDOR_STRING, vlen);
+		w.raw(vstr, vlen);
 		w.le32(m->data.vorbis_comment.num_comments);
 		for (unsigned i = 0; i < m->data.vorbis_comment.num_comments; i++) {
 			w.le32(m->data.vorbis_comment.comments[i].length);

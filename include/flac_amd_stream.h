@@ -504,6 +504,111 @@ FLAC__bool FLAC__metadata_object_picture_set_description(FLAC__StreamMetadata *o
 FLAC__bool FLAC__metadata_object_picture_set_data(FLAC__StreamMetadata *object, FLAC__byte *data, FLAC__uint32 length, FLAC__bool copy);
 FLAC__bool FLAC__metadata_object_picture_is_legal(const FLAC__StreamMetadata *object, const char **violation);
 
+/* ---- metadata level 1 and level 2: editing the metadata of a FLAC file in place (host code) ---- */
+#include <sys/types.h>
+/* include/FLAC/callback.h:85-176 */
+typedef void *FLAC__IOHandle;
+typedef size_t (*FLAC__IOCallback_Read)(void *ptr, size_t size, size_t nmemb, FLAC__IOHandle handle);
+typedef size_t (*FLAC__IOCallback_Write)(const void *ptr, size_t size, size_t nmemb, FLAC__IOHandle handle);
+typedef int (*FLAC__IOCallback_Seek)(FLAC__IOHandle handle, FLAC__int64 offset, int whence);
+typedef FLAC__int64 (*FLAC__IOCallback_Tell)(FLAC__IOHandle handle);
+typedef int (*FLAC__IOCallback_Eof)(FLAC__IOHandle handle);
+typedef int (*FLAC__IOCallback_Close)(FLAC__IOHandle handle);
+typedef struct {
+	FLAC__IOCallback_Read read;
+	FLAC__IOCallback_Write write;
+	FLAC__IOCallback_Seek seek;
+	FLAC__IOCallback_Tell tell;
+	FLAC__IOCallback_Eof eof;
+	FLAC__IOCallback_Close close;
+} FLAC__IOCallbacks;
+/* metadata.h:299-354 */
+struct FLAC__Metadata_SimpleIterator;
+typedef struct FLAC__Metadata_SimpleIterator FLAC__Metadata_SimpleIterator;
+typedef enum {
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_OK = 0,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_ILLEGAL_INPUT,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_ERROR_OPENING_FILE,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_NOT_A_FLAC_FILE,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_NOT_WRITABLE,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_BAD_METADATA,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_READ_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_SEEK_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_WRITE_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_RENAME_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_UNLINK_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_MEMORY_ALLOCATION_ERROR,
+	FLAC__METADATA_SIMPLE_ITERATOR_STATUS_INTERNAL_ERROR
+} FLAC__Metadata_SimpleIteratorStatus;
+extern const char *const FLAC__Metadata_SimpleIteratorStatusString[];
+/* metadata.h:364-648 */
+FLAC__Metadata_SimpleIterator *FLAC__metadata_simple_iterator_new(void);
+void FLAC__metadata_simple_iterator_delete(FLAC__Metadata_SimpleIterator *iterator);
+FLAC__Metadata_SimpleIteratorStatus FLAC__metadata_simple_iterator_status(FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_init(FLAC__Metadata_SimpleIterator *iterator, const char *filename, FLAC__bool read_only, FLAC__bool preserve_file_stats);
+FLAC__bool FLAC__metadata_simple_iterator_is_writable(const FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_next(FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_prev(FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_is_last(const FLAC__Metadata_SimpleIterator *iterator);
+off_t FLAC__metadata_simple_iterator_get_block_offset(const FLAC__Metadata_SimpleIterator *iterator);
+FLAC__MetadataType FLAC__metadata_simple_iterator_get_block_type(const FLAC__Metadata_SimpleIterator *iterator);
+unsigned FLAC__metadata_simple_iterator_get_block_length(const FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_get_application_id(FLAC__Metadata_SimpleIterator *iterator, FLAC__byte *id);
+FLAC__StreamMetadata *FLAC__metadata_simple_iterator_get_block(FLAC__Metadata_SimpleIterator *iterator);
+FLAC__bool FLAC__metadata_simple_iterator_set_block(FLAC__Metadata_SimpleIterator *iterator, FLAC__StreamMetadata *block, FLAC__bool use_padding);
+FLAC__bool FLAC__metadata_simple_iterator_insert_block_after(FLAC__Metadata_SimpleIterator *iterator, FLAC__StreamMetadata *block, FLAC__bool use_padding);
+FLAC__bool FLAC__metadata_simple_iterator_delete_block(FLAC__Metadata_SimpleIterator *iterator, FLAC__bool use_padding);
+/* metadata.h:703-780 */
+struct FLAC__Metadata_Chain;
+typedef struct FLAC__Metadata_Chain FLAC__Metadata_Chain;
+struct FLAC__Metadata_Iterator;
+typedef struct FLAC__Metadata_Iterator FLAC__Metadata_Iterator;
+typedef enum {
+	FLAC__METADATA_CHAIN_STATUS_OK = 0,
+	FLAC__METADATA_CHAIN_STATUS_ILLEGAL_INPUT,
+	FLAC__METADATA_CHAIN_STATUS_ERROR_OPENING_FILE,
+	FLAC__METADATA_CHAIN_STATUS_NOT_A_FLAC_FILE,
+	FLAC__METADATA_CHAIN_STATUS_NOT_WRITABLE,
+	FLAC__METADATA_CHAIN_STATUS_BAD_METADATA,
+	FLAC__METADATA_CHAIN_STATUS_READ_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_SEEK_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_WRITE_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_RENAME_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_UNLINK_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_MEMORY_ALLOCATION_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_INTERNAL_ERROR,
+	FLAC__METADATA_CHAIN_STATUS_INVALID_CALLBACKS,
+	FLAC__METADATA_CHAIN_STATUS_READ_WRITE_MISMATCH,
+	FLAC__METADATA_CHAIN_STATUS_WRONG_WRITE_CALL
+} FLAC__Metadata_ChainStatus;
+extern const char *const FLAC__Metadata_ChainStatusString[];
+/* metadata.h:798-1242; the two *_read_ogg* calls fail with ERROR_OPENING_FILE / INTERNAL_ERROR like a reference built
+ * without libogg */
+FLAC__Metadata_Chain *FLAC__metadata_chain_new(void);
+void FLAC__metadata_chain_delete(FLAC__Metadata_Chain *chain);
+FLAC__Metadata_ChainStatus FLAC__metadata_chain_status(FLAC__Metadata_Chain *chain);
+FLAC__bool FLAC__metadata_chain_read(FLAC__Metadata_Chain *chain, const char *filename);
+FLAC__bool FLAC__metadata_chain_read_ogg(FLAC__Metadata_Chain *chain, const char *filename);
+FLAC__bool FLAC__metadata_chain_read_with_callbacks(FLAC__Metadata_Chain *chain, FLAC__IOHandle handle, FLAC__IOCallbacks callbacks);
+FLAC__bool FLAC__metadata_chain_read_ogg_with_callbacks(FLAC__Metadata_Chain *chain, FLAC__IOHandle handle, FLAC__IOCallbacks callbacks);
+FLAC__bool FLAC__metadata_chain_check_if_tempfile_needed(FLAC__Metadata_Chain *chain, FLAC__bool use_padding);
+FLAC__bool FLAC__metadata_chain_write(FLAC__Metadata_Chain *chain, FLAC__bool use_padding, FLAC__bool preserve_file_stats);
+FLAC__bool FLAC__metadata_chain_write_with_callbacks(FLAC__Metadata_Chain *chain, FLAC__bool use_padding, FLAC__IOHandle handle, FLAC__IOCallbacks callbacks);
+FLAC__bool FLAC__metadata_chain_write_with_callbacks_and_tempfile(FLAC__Metadata_Chain *chain, FLAC__bool use_padding, FLAC__IOHandle handle, FLAC__IOCallbacks callbacks, FLAC__IOHandle temp_handle, FLAC__IOCallbacks temp_callbacks);
+void FLAC__metadata_chain_merge_padding(FLAC__Metadata_Chain *chain);
+void FLAC__metadata_chain_sort_padding(FLAC__Metadata_Chain *chain);
+FLAC__Metadata_Iterator *FLAC__metadata_iterator_new(void);
+void FLAC__metadata_iterator_delete(FLAC__Metadata_Iterator *iterator);
+void FLAC__metadata_iterator_init(FLAC__Metadata_Iterator *iterator, FLAC__Metadata_Chain *chain);
+FLAC__bool FLAC__metadata_iterator_next(FLAC__Metadata_Iterator *iterator);
+FLAC__bool FLAC__metadata_iterator_prev(FLAC__Metadata_Iterator *iterator);
+FLAC__MetadataType FLAC__metadata_iterator_get_block_type(const FLAC__Metadata_Iterator *iterator);
+FLAC__StreamMetadata *FLAC__metadata_iterator_get_block(FLAC__Metadata_Iterator *iterator);
+FLAC__bool FLAC__metadata_iterator_set_block(FLAC__Metadata_Iterator *iterator, FLAC__StreamMetadata *block);
+FLAC__bool FLAC__metadata_iterator_delete_block(FLAC__Metadata_Iterator *iterator, FLAC__bool replace_with_padding);
+FLAC__bool FLAC__metadata_iterator_insert_block_before(FLAC__Metadata_Iterator *iterator, FLAC__StreamMetadata *block);
+FLAC__bool FLAC__metadata_iterator_insert_block_after(FLAC__Metadata_Iterator *iterator, FLAC__StreamMetadata *block);
+
 #ifdef __cplusplus
 }
 #endif
