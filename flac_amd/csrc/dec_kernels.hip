@@ -1041,15 +1041,29 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 
 __global__ void k_dec_summary(const FaFrameCand *cands, const uint32_t *ncand_ptr, unsigned long long *result)
 {
-	// result[0] good frames, [1] wide samples in good frames, [2] bad candidates
+	// result[0] good frames, [1] wide samples in good frames, [2] bad candidates outside good frames
 	const uint32_t n = ncand_ptr[0];
 	unsigned long long good = 0, wide = 0, bad = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		if (cands[i].status == 1) {
 			good++;
 			wide += cands[i].blocksize;
-		} else
-			bad++;
+		} else {
+			// A sync pattern with a valid header CRC-8 inside the bytes of a good frame is not a frame: a
+			// reader that walks the stream (frame_sync_, stream_decoder.c:1941) never looks there.  The
+			// table is in byte order, so the nearest good frame in front decides.
+			bool shadowed = false;
+			for (uint32_t j = i; j-- > 0;) {
+				if (cands[j].stream != cands[i].stream)
+					break;
+				if (cands[j].status == 1) {
+					shadowed = cands[j].end_byte > cands[i].pos;
+					break;
+				}
+			}
+			if (!shadowed)
+				bad++;
+		}
 	}
 	if (good) atomicAdd(&result[0], good);
 	if (wide) atomicAdd(&result[1], wide);

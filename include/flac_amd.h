@@ -179,7 +179,9 @@ typedef struct {
 int flacamd_decoder_frames(flacamd_decoder *d, flacamd_frame_info *out, uint32_t capacity,
                            uint32_t *count, int *truncated);
 /* Blocks until the decode finished; reports frames decoded, wide samples written and the number
- * of frames whose CRC-16 or structure was bad (those are zero-filled, stream_decoder.c:2105-2113). */
+ * of frames whose CRC-16 or structure was bad (those are zero-filled, stream_decoder.c:2105-2113).
+ * A sync pattern that happens to carry a valid header CRC-8 inside the bytes of a good frame stays
+ * in the table of flacamd_decoder_frames (status 2 or 3) but is not a frame and is not counted. */
 int flacamd_decoder_result(flacamd_decoder *d, uint32_t *frames, uint64_t *wide_samples,
                            uint32_t *bad_frames);
 #define FLACAMD_DEC_STAGES 4

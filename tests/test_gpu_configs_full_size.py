@@ -201,3 +201,30 @@ def test_decoder_frames_per_wave(lw, monkeypatch):
             dec.close()
         assert (nfr, nwide, bad) == (len(frames), pcm.shape[0], 0), case["name"]
         assert np.array_equal(got, pcm), case["name"]
+
+
+def test_sync_pattern_inside_a_good_frame_is_not_a_bad_frame():
+    """One minute of eight 24-bit channels whose encoded bytes happen to hold, inside a frame, a sync pattern with a valid
+    header CRC-8: a reader that walks the stream never looks there (frame_sync_, stream_decoder.c:1941), so the batch decoder
+    must give back every sample and report no bad frame, although the pattern is in its table of frame headers."""
+    import ctypes as C
+    import flac_amd
+    import torch
+    wide = 192000 * 60
+    pcm = synth(99, wide, 8, 24, 192000)
+    p = flac_amd.preset(8, 8, 24, 192000)
+    dev, out, sizes, offs, nframes = gpu_encode(p, pcm, 4)
+    total = int(offs[nframes].item())
+    dec = flac_amd.Decoder(8, 24, p.blocksize, device=0, max_input_bytes=total + 64, max_frames=nframes + 64)
+    try:
+        back = torch.zeros_like(dev)
+        dec.decode_device(out.data_ptr(), total, [(0, total, 0, wide)], back.data_ptr(), 4, wide)
+        torch.cuda.synchronize()
+        assert dec.result() == (nframes, wide, 0)
+        assert torch.equal(back, dev)
+        rows = (C.c_uint64 * (6 * (nframes + 64)))()
+        count, cut = C.c_uint32(0), C.c_int(0)
+        assert flac_amd.lib().flacamd_decoder_frames(dec._h, rows, nframes + 64, C.byref(count), C.byref(cut)) == 0
+        assert count.value > nframes and cut.value == 0   # the pattern is listed, with a status that is not "good"
+    finally:
+        dec.close()
