@@ -237,6 +237,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_stream_api:
         try:
             result["end_to_end"] = bench_stream_api(flac_amd, pcm32)
+            result["end_to_end"]["without_md5"] = bench_stream_api(flac_amd, pcm32, do_md5=False)
         except Exception as exc:
             result["end_to_end"] = {"error": str(exc)}
 
@@ -261,9 +262,11 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_stream_api(flac_amd, pcm32):
+def bench_stream_api(flac_amd, pcm32, do_md5=True):
     """The same stream through the libFLAC-compatible API from host memory: int32 samples in,
-    MD5, PCIe both ways, write callbacks.  Never the headline value."""
+    MD5, PCIe both ways, write callbacks.  Never the headline value.  do_md5=False switches the
+    digest off (FLAC__stream_encoder_set_do_md5, stream_encoder.c:1414), which shows what the
+    copies and the GPU work take on their own."""
     import ctypes as C
     lib = flac_amd.lib()
     wide, ch = pcm32.shape
@@ -280,6 +283,8 @@ def bench_stream_api(flac_amd, pcm32):
     for name, v in (("channels", ch), ("bits_per_sample", BPS), ("sample_rate", RATE), ("compression_level", LEVEL)):
         getattr(lib, "FLAC__stream_encoder_set_" + name)(enc, C.c_uint(v))
     lib.FLAC__stream_encoder_set_total_samples_estimate(enc, C.c_uint64(wide))
+    if not do_md5:
+        lib.FLAC__stream_encoder_set_do_md5(enc, C.c_int(0))
     t0 = time.perf_counter()
     st = lib.FLAC__stream_encoder_init_stream(enc, cb, None, None, None, None)
     if st != 0:
@@ -295,8 +300,8 @@ def bench_stream_api(flac_amd, pcm32):
     t2 = time.perf_counter()
     lib.FLAC__stream_encoder_delete(enc)
     return {"value": wide * ch / (t2 - t1) / 1e6, "unit": "MSamples/s", "seconds": t2 - t1, "init_seconds": t1 - t0, "bytes": got[0],
-            "what": "FLAC__stream_encoder_process_interleaved of the same 600 s stream from host int32: MD5, host<->device copies and "
-                    "write callbacks included; one host thread"}
+            "what": "FLAC__stream_encoder_process_interleaved of the same 600 s stream from host int32: %shost<->device copies and "
+                    "write callbacks included; one host thread" % ("MD5, " if do_md5 else "no MD5, ")}
 
 
 def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev):
