@@ -80,6 +80,26 @@ int flacamd_pcm_unpack(const void *src_dev, const flacamd_pcm_format *fmt, uint6
 int flacamd_pcm_pack(const void *src_dev, uint32_t src_sample_bytes, uint32_t channels, uint32_t bits_per_sample,
                      uint32_t container, uint64_t wide_samples, void *dst_dev, void *stream);
 
+/* ---- ReplayGain analysis (host code: the loudness filter is a serial recurrence over the stream) ----
+ *
+ * The reference's own names and meanings.  Core: include/share/replaygain_analysis.h:33-52
+ * (src/share/replaygain_analysis/replaygain_analysis.c); one analysis at a time per process, as there.
+ * Gains are in dB relative to ReplayGainReferenceLoudness; GAIN_NOT_ENOUGH_SAMPLES is -24601. */
+extern float ReplayGainReferenceLoudness;
+int InitGainAnalysis(long samplefreq);                 /* 1 = ok, 0 = unsupported sample rate */
+int ResetSampleFrequency(long samplefreq);
+int AnalyzeSamples(const float *left_samples, const float *right_samples, size_t num_samples, int num_channels);
+float GetTitleGain(void);
+float GetAlbumGain(void);
+/* The wrappers the command line calls per decoded or encoded block
+ * (include/share/grabbag/replaygain.h:44-52, src/share/grabbag/replaygain.c:150-275): integer samples of
+ * `bps` bits, one array per channel; the peak is relative to full scale. */
+int grabbag__replaygain_is_valid_sample_frequency(unsigned sample_frequency);
+int grabbag__replaygain_init(unsigned sample_frequency);
+int grabbag__replaygain_analyze(const int32_t *const input[], int is_stereo, unsigned bps, unsigned samples);
+void grabbag__replaygain_get_album(float *gain, float *peak);
+void grabbag__replaygain_get_title(float *gain, float *peak);
+
 #ifdef __cplusplus
 }
 #endif
