@@ -498,7 +498,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			// on LDS between the levels. ----
 			const uint32_t wv = tid >> 6, ln = tid & 63;
 			const uint32_t tz = ln ? (uint32_t)__builtin_ctz(ln) : 0u;
-			for (uint32_t g = wv; g < ng; g += FA_THREADS / 64) {
+			auto price64 = [&](uint32_t g) {
 				const uint4 q = *(const uint4 *)(gq + 4 * g);
 				const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
 				uint64_t *gs = sums + (size_t)g * 2 * PF;
@@ -543,6 +543,71 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 				if (have_c) {
 					atomicAdd(&pbits[g * 16 + poc], bc);
 					gs[(2u << pm) - (2u << poc) + pc] = sc;   // the winner's parameters are derived from these
+				}
+			};
+			// Two candidates at a time, so that their chains of lane exchanges overlap; in 32-bit arithmetic
+			// when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32), which is always
+			// so for streams of up to 16 bits.
+			for (uint32_t g0 = wv; g0 < ng; g0 += 2 * (FA_THREADS / 64)) {
+				const uint32_t gb = g0 + FA_THREADS / 64;
+				const bool two = gb < ng;
+				const uint32_t gi[2] = {g0, two ? gb : g0};
+				uint4 q[2];
+				uint64_t f64[2];
+				bool mine[2];
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					q[c] = *(const uint4 *)(gq + 4 * gi[c]);
+					mine[c] = ln < (1u << (q[c].x & 0xff));
+					f64[c] = mine[c] ? sums[(size_t)gi[c] * 2 * PF + ln] : 0ull;
+					if (q[c].x >> 16)
+						f64[c] &= 0xffffffffull;   // the reference's 32-bit accumulator (stream_encoder.c:3803-3833)
+				}
+				if (!__all(((f64[0] | f64[1]) >> 26) == 0)) {
+					price64(g0);
+					if (two)
+						price64(gb);
+					continue;
+				}
+				uint32_t v[2][7];
+#pragma unroll
+				for (int c = 0; c < 2; c++)
+					v[c][0] = (uint32_t)f64[c];
+#pragma unroll
+				for (int j = 0; j < 6; j++)
+#pragma unroll
+					for (int c = 0; c < 2; c++)
+						v[c][j + 1] = v[c][j] + (uint32_t)__shfl_xor((int)v[c][j], 1 << j, 64);
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					if (c == 1 && !two)
+						break;
+					const uint32_t g = gi[c];
+					const uint32_t pm = q[c].x & 0xff, pmn = (q[c].x >> 8) & 0xff;
+					uint64_t *gs = sums + (size_t)g * 2 * PF;
+					uint32_t sc = v[c][1];
+#pragma unroll
+					for (int j = 1; j < 6; j++)
+						sc = tz == (uint32_t)j ? v[c][j + 1] : sc;
+					const int lc = (int)pm - 1 - (int)tz;
+					const bool have_c = mine[c] && ln != 0 && lc >= (int)pmn;
+					const uint32_t poc = have_c ? (uint32_t)lc : 0u;
+					const uint32_t pc = ln >> (tz + 1);
+					const uint32_t nf = (bsf >> pm) - (ln == 0 ? q[c].y : 0u);
+					const uint32_t nc = (bsf >> poc) - (pc == 0 ? q[c].y : 0u);
+					const uint32_t kf = (pm == 0) ? q[c].z : rice_k_from_sum32(v[c][0], nf, P.rice_limit);
+					const uint32_t kc = (poc == 0) ? q[c].z : rice_k_from_sum32(sc, nc, P.rice_limit);
+					const uint32_t bf = rice_bits_estimate32(kf, nf, v[c][0]);
+					const uint32_t bc = rice_bits_estimate32(kc, nc, sc);
+					if (mine[c]) {
+						atomicAdd(&pbits[g * 16 + pm], bf);
+						if (q[c].x >> 16)
+							gs[ln] = v[c][0];
+					}
+					if (have_c) {
+						atomicAdd(&pbits[g * 16 + poc], bc);
+						gs[(2u << pm) - (2u << poc) + pc] = sc;   // the winner's parameters are derived from these
+					}
 				}
 			}
 		} else {
