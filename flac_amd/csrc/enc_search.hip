@@ -359,10 +359,20 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			gq[4 * g + 2] = c.seed;
 			gq[4 * g + 3] = 0;
 		}
-		if (!alias) {
-			for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
-				sums[e] = 0;
-		}
+		// Clearing the sums before the residuals add into them.  With at most 64 finest partitions the
+		// coarser levels are written, not added to, so only each candidate's finest sums need it.
+		auto clear_sums = [&]() {
+			if (PF >= 2 && PF <= 64) {
+				const uint32_t half = PF / 2;   // 16-byte stores: two sums each
+				for (uint32_t e = tid; e < ng * half; e += FA_THREADS)
+					((uint4 *)sums)[(e / half) * PF + (e % half)] = make_uint4(0, 0, 0, 0);
+			} else {
+				for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
+					sums[e] = 0;
+			}
+		};
+		if (!alias)
+			clear_sums();
 		STAMP(3);
 
 		// ---- residuals of every candidate of the group, tile by tile, all in registers ----
@@ -381,8 +391,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			if (alias) {
 				// the sums take over the stage area once every thread holds its samples
 				__syncthreads();
-				for (uint32_t e = tid; e < ng * 2 * PF; e += FA_THREADS)
-					sums[e] = 0;
+				clear_sums();
 				__syncthreads();
 			}
 			STAMP(4);
