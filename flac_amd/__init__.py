@@ -37,7 +37,11 @@ class StreamDesc(C.Structure):
 
 
 class FlacAmdError(RuntimeError):
-    pass
+    """A refused call; `code` is the library's negative FLACAMD_E_* value."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 _lib = None
@@ -70,7 +74,7 @@ def lib():
 
 def _check(rc):
     if rc != 0:
-        raise FlacAmdError("flac_amd error %d: %s" % (rc, lib().flacamd_last_error().decode()))
+        raise FlacAmdError("flac_amd error %d: %s" % (rc, lib().flacamd_last_error().decode()), rc)
 
 
 def preset(level, channels, bits_per_sample, sample_rate, blocksize=0, **over):

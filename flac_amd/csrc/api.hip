@@ -147,9 +147,16 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	int rc = flacamd_params_resolve(&p);
 	if (rc)
 		return rc;
-	if (p.max_residual_partition_order > FLACAMD_MAX_PARTITION_ORDER)
-		return fa_fail(FLACAMD_E_UNSUPPORTED, "max Rice partition order %u exceeds the device limit %d", p.max_residual_partition_order,
-		               FLACAMD_MAX_PARTITION_ORDER);
+	{
+		// what counts is the order a full block can reach: the setting, capped by how often the
+		// blocksize halves evenly (stream_encoder.c:2929-2936)
+		uint32_t reach = 0;
+		while (reach < p.max_residual_partition_order && !((p.blocksize >> reach) & 1))
+			reach++;
+		if (reach > FLACAMD_MAX_PARTITION_ORDER)
+			return fa_fail(FLACAMD_E_UNSUPPORTED, "Rice partition order %u (blocksize %u, max order setting %u) exceeds the device limit %d", reach,
+			               p.blocksize, p.max_residual_partition_order, FLACAMD_MAX_PARTITION_ORDER);
+	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		return fa_fail(FLACAMD_E_DEVICE, "no HIP device available: the FLAC engine needs an AMD GPU");

@@ -22,7 +22,9 @@ extern "C" {
 #define FLACAMD_MAX_LPC_ORDER 32
 #define FLACAMD_MAX_APODIZATIONS 32
 /* Largest Rice partition order the device path evaluates (the FLAC subset limit,
- * include/FLAC/format.h:119 FLAC__SUBSET_MAX_RICE_PARTITION_ORDER). */
+ * include/FLAC/format.h:119 FLAC__SUBSET_MAX_RICE_PARTITION_ORDER).  It bounds the order a block can
+ * reach - the setting capped by how often the blocksize halves evenly (stream_encoder.c:2929-2936) -
+ * so a setting of 15 with blocksize 1152 (order 7 at most) is accepted. */
 #define FLACAMD_MAX_PARTITION_ORDER 8
 
 enum {
