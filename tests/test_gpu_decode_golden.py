@@ -86,3 +86,103 @@ def test_corrupt_frame_is_dropped_not_propagated():
     assert np.array_equal(out[:4096], pcm[:4096])
     assert not out[4096:8192].any()          # the damaged frame reads as zeros (stream_decoder.c:2105-2113)
     assert np.array_equal(out[8192:], pcm[8192:])
+
+
+def _crc8(data):
+    c = 0
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = ((c << 1) ^ 0x07) & 0xff if c & 0x80 else (c << 1) & 0xff
+    return c
+
+
+def _header_bytes(f):
+    """Length of the frame header of f, CRC-8 included, as the header's own codes give it (frame.c layout)."""
+    x = f[4]
+    n = 4 + (1 if x < 0x80 else 2 if x < 0xe0 else 3 if x < 0xf0 else 4 if x < 0xf8 else 5 if x < 0xfc else 6 if x < 0xfe else 7)
+    bs, sr = f[2] >> 4, f[2] & 15
+    n += 1 if bs == 6 else 2 if bs == 7 else 0
+    n += 1 if sr == 12 else 2 if sr in (13, 14) else 0
+    return n + 1
+
+
+def _damage(frame, rng):
+    """One frame with the same length, damaged so that it is no longer a valid frame (the CRC-16 covers every bit)."""
+    f = bytearray(frame)
+    hb = _header_bytes(f)
+    kind = rng.integers(0, 7)
+    if kind == 0:      # a few flipped bits after the header, within 2 KiB of each other: two flipped bits 32767 bits
+        #               apart, the period of the CRC-16 polynomial, make a frame that is valid for the reference too
+        at = int(rng.integers(hb, len(f)))
+        for _ in range(int(rng.integers(1, 4))):
+            f[int(rng.integers(at, min(at + 2048, len(f))))] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:    # other blocksize / sample rate codes under a header CRC that is right again
+        f[2] = int(rng.integers(0x10, 0xff))
+        if (f[2] & 15) == 15:
+            f[2] &= 0xfe
+        hb = min(_header_bytes(f), len(f) - 1)
+        f[hb - 1] = _crc8(f[:hb - 1])
+    elif kind == 2:    # another channel assignment, same channel count where there is one, header CRC right again
+        f[3] = (f[3] & 0x0f) | (int(rng.integers(8, 11)) << 4 if f[3] >> 4 in (1, 8, 9, 10) else f[3] & 0xf0)
+        f[hb - 1] = _crc8(f[:hb - 1])
+        f[int(rng.integers(hb, len(f)))] ^= 0x10
+    elif kind == 3:    # any subframe type byte: reserved types, LPC order 32, wasted-bits flag
+        f[hb] = int(rng.integers(0, 256))
+        f[hb + 1] ^= 0xff
+    elif kind == 4:    # the rest of the frame is zeros: one unary run to the end of the frame and beyond
+        at = int(rng.integers(hb, len(f)))
+        f[at:] = bytes(len(f) - at)
+    elif kind == 5:    # the rest of the frame is ones: empty unary codes, escape codes, 31-bit parameters
+        at = int(rng.integers(hb, len(f)))
+        f[at:] = b"\xff" * (len(f) - at)
+    else:              # the rest of the frame is noise
+        at = int(rng.integers(hb, len(f)))
+        f[at:] = rng.integers(0, 256, len(f) - at, dtype=np.uint8).tobytes()
+    if bytes(f) == bytes(frame):
+        f[-1] ^= 1
+    return bytes(f)
+
+
+def _synthetic_stream(channels, bps, rate, bs, level, nframes, seed):
+    """PCM (tones plus noise, one silent stretch) and its frames from this library's own encoder, whose output the
+    encoder tests pin to the reference's."""
+    import flac_amd
+    rng = np.random.default_rng(seed)
+    n = nframes * bs - bs // 3
+    t = np.arange(n)[:, None]
+    amp = (1 << (bps - 1)) * 0.4
+    pcm = amp * np.sin(t * (0.01 + 0.003 * np.arange(channels)[None, :])) + rng.normal(0, amp / 50, (n, channels))
+    pcm[5 * bs:6 * bs + 7] = 0
+    pcm = np.clip(np.rint(pcm), -(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int32)
+    enc = flac_amd.Encoder(flac_amd.preset(level, channels, bps, rate, bs), device=0, max_frames=nframes)
+    try:
+        frames, _ = enc.encode_host(pcm)
+    finally:
+        enc.close()
+    assert len(frames) == nframes
+    return pcm, frames
+
+
+@pytest.mark.parametrize("channels,bps,rate,bs,level", [(2, 16, 44100, 4096, 8), (2, 24, 96000, 4096, 8), (8, 24, 96000, 1152, 5),
+                                                        (1, 8, 22050, 576, 5), (2, 16, 44100, 257, 3), (2, 16, 44100, 4096, 0)])
+def test_damaged_frames_leave_their_neighbours_alone(channels, bps, rate, bs, level):
+    """Every second frame damaged in a random way, several times over: the damaged frames are dropped (zeros,
+    stream_decoder.c:2105-2113), the frames between them come out bit-exact, and nothing reads or writes out of bounds."""
+    import flac_amd
+    nframes = 48
+    pcm, frames = _synthetic_stream(channels, bps, rate, bs, level, nframes, bs + bps)
+    n = pcm.shape[0]
+    want = pcm.copy()
+    for k in range(1, nframes, 2):
+        want[k * bs:(k + 1) * bs] = 0
+    dec = flac_amd.Decoder(channels, bps, bs, device=0, max_input_bytes=sum(map(len, frames)) + 64, max_frames=4 * nframes + 64)
+    try:
+        for seed in range(40):
+            rng = np.random.default_rng(seed)
+            blob = b"".join(_damage(f, rng) if k % 2 else f for k, f in enumerate(frames))
+            out, nfr, _wide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=4)
+            assert nfr == nframes // 2 and bad >= 1, "seed %d: %d frames, %d bad" % (seed, nfr, bad)
+            assert np.array_equal(out, want), "seed %d" % seed
+    finally:
+        dec.close()
