@@ -94,6 +94,38 @@ bool read_header(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__bool *is_last
 	return true;
 }
 
+// `n` bytes (plus `extra` zero bytes at the end) into a fresh buffer that grows as the bytes arrive: a length field of a
+// damaged file cannot make the process reserve more memory than the file backs up.  Same results as reading into one
+// malloc(n): READ_ERROR when the file ends early.
+SStatus read_blob(FLAC__IOHandle h, FLAC__IOCallback_Read rd, size_t n, size_t extra, FLAC__byte **out)
+{
+	const size_t kStep = (size_t)1 << 20;
+	size_t cap = (n < kStep ? n : kStep) + extra, have = 0;
+	FLAC__byte *p = (FLAC__byte *)malloc(cap ? cap : 1);
+	if (!p) return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_MEMORY_ALLOCATION_ERROR;
+	while (have < n) {
+		const size_t want = n - have < kStep ? n - have : kStep;
+		if (have + want + extra > cap) {
+			cap = have + want + extra > 2 * cap ? have + want + extra : 2 * cap;
+			if (cap > n + extra) cap = n + extra;
+			FLAC__byte *q = (FLAC__byte *)realloc(p, cap);
+			if (!q) {
+				free(p);
+				return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_MEMORY_ALLOCATION_ERROR;
+			}
+			p = q;
+		}
+		if (rd(p + have, 1, want, h) != want) {
+			free(p);
+			return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_READ_ERROR;
+		}
+		have += want;
+	}
+	memset(p + n, 0, extra);
+	*out = p;
+	return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_OK;
+}
+
 SStatus read_entry(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__StreamMetadata_VorbisComment_Entry *e)
 {
 	FLAC__byte b[4];
@@ -102,13 +134,8 @@ SStatus read_entry(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__StreamMetad
 	e->length = le32(b);
 	free(e->entry);
 	e->entry = 0;
-	if (e->length) {
-		if ((size_t)e->length + 1 < e->length || !(e->entry = (FLAC__byte *)malloc((size_t)e->length + 1)))
-			return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_MEMORY_ALLOCATION_ERROR;
-		if (rd(e->entry, 1, e->length, h) != e->length)
-			return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_READ_ERROR;
-		e->entry[e->length] = 0;
-	}
+	if (e->length)
+		return read_blob(h, rd, e->length, 1, &e->entry);
 	return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_OK;
 }
 
@@ -120,12 +147,8 @@ SStatus read_cstring(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__byte **da
 		return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_READ_ERROR;
 	*length = (FLAC__uint32)be(b, 4);
 	free(*data);
-	if (!(*data = (FLAC__byte *)malloc((size_t)*length + 1)))
-		return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_MEMORY_ALLOCATION_ERROR;
-	if (*length && rd(*data, 1, *length, h) != *length)
-		return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_READ_ERROR;
-	(*data)[*length] = 0;
-	return FLAC__METADATA_SIMPLE_ITERATOR_STATUS_OK;
+	*data = 0;
+	return read_blob(h, rd, *length, 1, data);
 }
 
 // read_metadata_block_data_cb_ (metadata_iterators.c:2105-2490): the body of a block whose type and
@@ -182,12 +205,23 @@ SStatus read_body(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__IOCallback_S
 		if (rd(b, 1, 4, h) != 4) return RD;
 		v.num_comments = le32(b);
 		v.comments = 0;
-		if (v.num_comments && !(v.comments = (FLAC__StreamMetadata_VorbisComment_Entry *)calloc(v.num_comments, sizeof *v.comments))) {
-			v.num_comments = 0;
-			return MEM;
-		}
-		for (unsigned i = 0; i < v.num_comments; i++)
+		// the array grows with the entries that are really there (each takes four bytes of file at least), so that a
+		// damaged count cannot reserve 64 GiB; num_comments is what the array holds if reading stops early
+		const unsigned declared = v.num_comments;
+		unsigned cap = 0;
+		v.num_comments = 0;
+		for (unsigned i = 0; i < declared; i++) {
+			if (i == cap) {
+				const unsigned ncap = cap ? (cap > declared / 2 ? declared : 2 * cap) : (declared < 1024 ? declared : 1024);
+				void *q = realloc(v.comments, (size_t)ncap * sizeof *v.comments);
+				if (!q) return MEM;
+				v.comments = (FLAC__StreamMetadata_VorbisComment_Entry *)q;
+				memset(v.comments + cap, 0, (size_t)(ncap - cap) * sizeof *v.comments);
+				cap = ncap;
+			}
+			v.num_comments = i + 1;
 			if ((st = read_entry(h, rd, v.comments + i)) != OK) return st;
+		}
 		return OK;
 	}
 	case FLAC__METADATA_TYPE_CUESHEET: {
@@ -245,10 +279,8 @@ SStatus read_body(FLAC__IOHandle h, FLAC__IOCallback_Read rd, FLAC__IOCallback_S
 		p.data_length = (FLAC__uint32)be(b + 16, 4);
 		free(p.data);
 		p.data = 0;
-		if (p.data_length) {
-			if (!(p.data = (FLAC__byte *)malloc(p.data_length))) return MEM;
-			if (rd(p.data, 1, p.data_length, h) != p.data_length) return RD;
-		}
+		if (p.data_length)
+			return read_blob(h, rd, p.data_length, 0, &p.data);
 		return OK;
 	}
 	default:

@@ -450,6 +450,34 @@ bool read_seektable(FLAC__StreamDecoder *d, FLAC__bool is_last, unsigned length)
 	return length ? skip_block(d, length) : true;
 }
 
+// n bytes of the block, followed by `extra` zero bytes, into a buffer that grows as the bytes arrive: a length field of a
+// damaged stream cannot reserve more memory than the stream backs up.  *out is set (and owned by the caller) even when
+// the input ends early.
+bool read_blob(FLAC__StreamDecoder *d, size_t n, size_t extra, FLAC__byte **out)
+{
+	const size_t kStep = (size_t)1 << 20;
+	size_t cap = (n < kStep ? n : kStep) + extra, have = 0;
+	if (0 == (*out = (FLAC__byte *)malloc(cap ? cap : 1)))
+		return alloc_fail(d);
+	while (have < n) {
+		const size_t want = n - have < kStep ? n - have : kStep;
+		if (have + want + extra > cap) {
+			cap = have + want + extra > 2 * cap ? have + want + extra : 2 * cap;
+			if (cap > n + extra)
+				cap = n + extra;
+			FLAC__byte *nb = (FLAC__byte *)realloc(*out, cap);
+			if (!nb)
+				return alloc_fail(d);
+			*out = nb;
+		}
+		if (!read_block(d, *out + have, want))
+			return false;
+		have += want;
+	}
+	memset(*out + n, 0, extra);
+	return true;
+}
+
 bool read_vc_entry(FLAC__StreamDecoder *d, FLAC__StreamMetadata_VorbisComment_Entry *e)
 {
 	if (!read_le32(d, &e->length))
@@ -458,12 +486,7 @@ bool read_vc_entry(FLAC__StreamDecoder *d, FLAC__StreamMetadata_VorbisComment_En
 		e->entry = 0;
 		return true;
 	}
-	if ((size_t)e->length + 1 < (size_t)e->length || 0 == (e->entry = (FLAC__byte *)malloc((size_t)e->length + 1)))
-		return alloc_fail(d);
-	if (!read_block(d, e->entry, e->length))
-		return false;
-	e->entry[e->length] = 0;
-	return true;
+	return read_blob(d, e->length, 1, &e->entry);
 }
 
 // read_metadata_vorbiscomment_ (stream_decoder.c:1711)
@@ -474,16 +497,24 @@ bool read_vorbiscomment(FLAC__StreamDecoder *d, FLAC__StreamMetadata_VorbisComme
 	if (!read_le32(d, &o->num_comments))
 		return false;
 	o->comments = 0;
-	if (o->num_comments) {
-		// every comment takes at least its 4 length bytes; refuse counts the input cannot hold
-		o->comments = (FLAC__StreamMetadata_VorbisComment_Entry *)calloc(o->num_comments, sizeof *o->comments);
-		if (!o->comments) {
-			o->num_comments = 0;
-			return alloc_fail(d);
+	// the array grows with the comments that are really there (each takes four bytes of input at least), so a damaged
+	// count cannot reserve 64 GiB; num_comments is what the array holds if reading stops early
+	const FLAC__uint32 declared = o->num_comments;
+	FLAC__uint32 cap = 0;
+	o->num_comments = 0;
+	for (FLAC__uint32 i = 0; i < declared; i++) {
+		if (i == cap) {
+			const FLAC__uint32 ncap = cap ? (cap > declared / 2 ? declared : 2 * cap) : (declared < 1024 ? declared : 1024);
+			void *nb = realloc(o->comments, (size_t)ncap * sizeof *o->comments);
+			if (!nb)
+				return alloc_fail(d);
+			o->comments = (FLAC__StreamMetadata_VorbisComment_Entry *)nb;
+			memset(o->comments + cap, 0, (size_t)(ncap - cap) * sizeof *o->comments);
+			cap = ncap;
 		}
-		for (FLAC__uint32 i = 0; i < o->num_comments; i++)
-			if (!read_vc_entry(d, &o->comments[i]))
-				return false;
+		o->num_comments = i + 1;
+		if (!read_vc_entry(d, &o->comments[i]))
+			return false;
 	}
 	return true;
 }
@@ -547,26 +578,16 @@ bool read_picture(FLAC__StreamDecoder *d, FLAC__StreamMetadata_Picture *o)
 	o->type = (FLAC__StreamMetadata_Picture_Type)x;
 	if (!read_be32(d, 4, &x))
 		return false;
-	if (0 == (o->mime_type = (char *)malloc((size_t)x + 1)))
-		return alloc_fail(d);
-	if (x && !read_block(d, (FLAC__byte *)o->mime_type, x))
+	if (!read_blob(d, x, 1, (FLAC__byte **)&o->mime_type))
 		return false;
-	o->mime_type[x] = 0;
 	if (!read_be32(d, 4, &x))
 		return false;
-	if (0 == (o->description = (FLAC__byte *)malloc((size_t)x + 1)))
-		return alloc_fail(d);
-	if (x && !read_block(d, o->description, x))
+	if (!read_blob(d, x, 1, &o->description))
 		return false;
-	o->description[x] = 0;
 	if (!read_be32(d, 4, &o->width) || !read_be32(d, 4, &o->height) || !read_be32(d, 4, &o->depth) || !read_be32(d, 4, &o->colors) ||
 	    !read_be32(d, 4, &o->data_length))
 		return false;
-	if (0 == (o->data = (FLAC__byte *)malloc(o->data_length ? o->data_length : 1)))
-		return alloc_fail(d);
-	if (o->data_length && !read_block(d, o->data, o->data_length))
-		return false;
-	return true;
+	return read_blob(d, o->data_length, 0, &o->data);
 }
 
 void free_block_contents(FLAC__StreamMetadata *b)
