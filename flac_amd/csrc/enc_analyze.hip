@@ -189,6 +189,8 @@ __device__ __forceinline__ void quad_split(uint32_t w, int32_t (&x)[4])
 	x[3] = l - r;
 }
 
+// Wave priority: load issue and the reductions ahead of the other workgroups' difference sums (0.130 -> 0.128 ms).
+#define QPRIO(n) __builtin_amdgcn_s_setprio(n)
 __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
 {
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 	constexpr uint32_t HP = ST_HP(4);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
 
+	QPRIO(3);
 	int32_t first[4];
 	quad_split(words[0], first);
 	uint32_t orv[4] = {0, 0, 0, 0}, ne[4] = {0, 0, 0, 0};
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 				continue;
 			int32_t raw[4 + FA_CHUNK];
 			load_chunk_lds<4>(raw, (const int32_t *)stage);
+			QPRIO(0);
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
 				uint32_t d[4 + FA_CHUNK];
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 			}
 		}
 	}
+	QPRIO(3);
 #pragma unroll
 	for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -376,6 +381,9 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 typedef float fa_f2 __attribute__((ext_vector_type(2)));
 typedef float fa_f4 __attribute__((ext_vector_type(4)));
 
+// Wave priority: staging (global loads in flight, LDS stores, the barrier) runs ahead of the other workgroups'
+// multiply-add loops on the same SIMD, which only wait for LDS anyway (measured 0.157 -> 0.144 ms).
+#define APRIO(n) __builtin_amdgcn_s_setprio(n)
 __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
                                                        const float *windows, float *autoc, uint32_t rows_per_block, uint32_t G)
 {
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 		}
 	};
 
+	APRIO(3);
 	if (quad) {
 		quad_load(0);
 		quad_store(0, xs);
@@ -490,6 +499,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 		const bool more = t + 1 < ntiles;
 		if (more && quad)
 			quad_load(t + 1);
+		APRIO(0);
 		if (active) {
 			const float *row = cur_buf + (size_t)my_j * row_pairs * 2;
 			if (!odd) {
@@ -514,6 +524,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 				}
 			}
 		}
+		APRIO(3);
 		if (more) {
 			if (quad)
 				quad_store(t + 1, next_buf);

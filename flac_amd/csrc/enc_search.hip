@@ -123,6 +123,15 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 #ifndef SEARCH_WAVES
 #define SEARCH_WAVES 4
 #endif
+// Wave priorities: the phases either side of the residual loop are chains of dependent loads, LDS round trips and
+// barriers with few instructions; the residual loop is issue-heavy.  With four workgroups sharing each SIMD, letting the
+// short phases issue ahead of the other workgroups' residual loops shortens every workgroup's critical path and costs the
+// loops nothing they would not have waited for anyway (measured: 0.828 -> 0.783 ms; the reverse assignment gains nothing).
+#ifndef SEARCH_PRIO_EDGE
+#define SEARCH_PRIO_EDGE 3
+#define SEARCH_PRIO_LOOP 0
+#endif
+#define SPRIO(n) __builtin_amdgcn_s_setprio(n)
 
 // PAIRS: the PCM is 16-bit stereo read as one 32-bit word per wide sample (a compile-time fact
 // here, so that the other sample formats' code does not weigh on register allocation)
@@ -166,6 +175,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 	const int32_t *my_coefs = coefs + (size_t)task * ncoef_all;
 
 	STAMP(0);
+	SPRIO(SEARCH_PRIO_EDGE);
 	// ---- everything this workgroup reads from global memory, requested up front ----
 	FaLpcCand pre_c;
 	pre_c.valid = 0;
@@ -397,6 +407,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			STAMP(4);
 			if (!have)
 				continue;
+			SPRIO(SEARCH_PRIO_LOOP);
 			const uint32_t bias = 0x80000000u;
 			uint32_t db[FA_CHUNK];
 #pragma unroll
@@ -490,6 +501,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			}
 		}
 		STAMP(5);
+		SPRIO(SEARCH_PRIO_EDGE);
 		__syncthreads();
 		STAMP(6);
 		{
