@@ -316,8 +316,10 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 // ---------------------------------------------------------------------------------------------
 // bit reader (bitreader.c): MSB-first bits out of big-endian 32-bit words.
 //
-// A lane keeps the next 32..64 bits of its frame in a register pair and the word after those in a
-// third register.  Words come from a per-lane ring in LDS that the whole wave refills together: 64
+// A lane keeps two consecutive words of its frame in registers and counts the unread bits of the
+// first (0..31); the next 32 bits of the stream are one v_alignbit_b32 of the pair, and moving on
+// by up to 32 bits is a subtraction plus, when a word boundary is crossed, a step to the next word:
+// no 64-bit shifts.  Words come from a per-lane ring in LDS that the whole wave refills together: 64
 // lanes fetch 64 consecutive words of ONE lane's frame in a single coalesced load, between blocks of
 // samples, long before that lane gets there.  A lane that outruns its ring (a very long unary run)
 // reads global memory itself.
@@ -330,9 +332,9 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 struct BitRd {
 	const uint32_t *wg;  // the frame's first word in global memory (word index wbase of the input)
 	uint64_t wbase;      // index of that word in the input
-	uint64_t buf;        // window, left-aligned: bit 63 is the next unread bit
-	uint32_t avail;      // valid bits in buf; 33..64 after br_refill
-	uint32_t nxt;        // the word that follows the window (already byte-swapped)
+	uint32_t cur;        // the word being read: its last `rem` bits are unread
+	uint32_t nxt;        // the word after it, all unread (both already byte-swapped)
+	uint32_t rem;        // 0..31
 	uint32_t wrel;       // index, relative to wbase, of the word after nxt
 	uint32_t nrel;       // words from wbase to the end of the input (saturated)
 	uint32_t limit;      // words [0, limit) have been in the ring; the last RING_WORDS of them still are
@@ -341,9 +343,9 @@ struct BitRd {
 	bool err;
 };
 
-// Bits consumed, counted from the start of word wbase: the window and the word after it are words
-// [.., wrel) of the frame, of which `avail` + 32 bits are still unread.
-__device__ __forceinline__ uint32_t br_pos(const BitRd &r) { return 32u * (r.wrel - 1u) - r.avail; }
+// Bits consumed, counted from the start of word wbase: cur and nxt are words wrel-2 and wrel-1 of the frame, of which
+// rem + 32 bits are still unread.
+__device__ __forceinline__ uint32_t br_pos(const BitRd &r) { return 32u * (r.wrel - 1u) - r.rem; }
 
 // The refill protocol keeps limit - RING_WORDS <= wrel, so one compare tells whether the ring has
 // the word; a lane that has outrun its ring reads global memory itself.
@@ -363,36 +365,33 @@ __device__ __forceinline__ void br_start(BitRd &r, uint32_t sbit)
 {
 	r.err = false;
 	const uint32_t i = sbit >> 5, s = sbit & 31;
-	const uint64_t two = ((uint64_t)r.ring[i] << 32) | r.ring[i + 1];
-	r.buf = two << s;
-	r.avail = 64 - s;
-	r.nxt = r.ring[i + 2];
-	r.wrel = i + 3;
+	// a position on a word boundary is "nothing left of the word before"
+	r.cur = s ? r.ring[i] : 0u;
+	r.nxt = r.ring[s ? i + 1 : i];
+	r.rem = (32u - s) & 31u;
+	r.wrel = s ? i + 2 : i + 1;
 }
 
-// afterwards the window holds at least 33 bits
-__device__ __forceinline__ void br_refill(BitRd &r)
-{
-	if (r.avail <= 32) {
-		r.buf |= (uint64_t)r.nxt << (32 - r.avail);
-		r.avail += 32;
-		r.nxt = br_fetch(r);
-	}
-}
+// the next 32 bits: the last rem bits of cur, then the first 32 - rem of nxt (one v_alignbit_b32)
+__device__ __forceinline__ uint32_t br_peek(const BitRd &r) { return __builtin_amdgcn_alignbit(r.cur, r.nxt, r.rem); }
 
-// n <= 32, after br_refill
+// n <= 32
 __device__ __forceinline__ void br_drop(BitRd &r, uint32_t n)
 {
-	r.buf <<= n;
-	r.avail -= n;
+	const int32_t left = (int32_t)r.rem - (int32_t)n;
+	if (left < 0) {
+		r.cur = r.nxt;
+		r.nxt = br_fetch(r);
+	}
+	r.rem = (uint32_t)left & 31u;
 }
 
+// n <= 32
 __device__ __forceinline__ uint32_t br_get(BitRd &r, uint32_t n)
 {
 	if (n == 0)
 		return 0;
-	br_refill(r);
-	const uint32_t v = (uint32_t)(r.buf >> (64 - n));
+	const uint32_t v = br_peek(r) >> (32 - n);
 	br_drop(r, n);
 	return v;
 }
@@ -410,8 +409,7 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 {
 	uint32_t n = 0;
 	for (;;) {
-		br_refill(r);
-		const uint32_t hi = (uint32_t)(r.buf >> 32);
+		const uint32_t hi = br_peek(r);
 		if (hi) {
 			const uint32_t z = (uint32_t)__clz((int)hi);
 			br_drop(r, z + 1);
@@ -493,11 +491,12 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 // fixed predictor is the LPC filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 in wrapping
 // 32-bit arithmetic).  M bounds the predictor orders present in the wave.
 //
-// The common case runs without control flow: every lane cuts a Rice symbol out of its 33..64-bit
-// window (one count of leading zeros, two shifts), predicts, shifts its history and tops the window
-// up from the ring word requested at the start of the sample.  Lanes for which that is not the right
+// The common case runs without control flow: every lane cuts a Rice symbol out of the next 32 bits
+// (one count of leading zeros, a saturating add, one bit-field extract), predicts, shifts its history
+// and, if the symbol ended in the next word, steps on with the ring word requested at the start of the
+// sample.  Lanes for which that is not the right
 // thing at this sample (warm-up and verbatim samples, a partition boundary, an escaped partition,
-// a symbol longer than the window, a ring that has fallen behind) throw the result away and take
+// a symbol longer than 32 bits, a ring that has fallen behind) throw the result away and take
 // the one divergent region, which uses the general bit reader.  Because the prediction and the
 // history shift run for all lanes on every sample, the history is renamed across the unrolled
 // samples rather than moved.
@@ -525,7 +524,6 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	uint32_t seg_end = 0, fast_end = 0;
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
-	br_refill(r);
 	// lanes that carry no frame write their block samples to a spare area
 	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * DEC_MAXLW];
 	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
@@ -535,28 +533,34 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			work_end = 0;
 			seg_end = 0;
 		}
-		// the fast path takes at most two words per sample
+		// the fast path takes at most one word per sample
 		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 #pragma unroll 4
 		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
 			const uint32_t i = i0 + s;
-			// the word a refill at the end of this sample would take
+			// the word a step into the next word at the end of this sample would bring in
 			const uint32_t ring_word = r.ring[r.wrel & (RING_WORDS - 1)];
-			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the top 32 bits of
-			// the window (which always holds at least 33): count of leading zeros (64 stands for
-			// "none of the 32 is set", which fails the length test), stop bit, k low bits
-			const uint32_t hi = (uint32_t)(r.buf >> 32);
-			uint32_t z;
-			asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(hi));
-			z = z < 64u ? z : 64u;
-			const uint32_t total = z + kp1;
+			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the next 32 bits: count of
+			// leading zeros (all ones for "none of the 32 is set": the saturating add then fails the length test),
+			// stop bit, k low bits
+			const uint32_t win = br_peek(r);
+			uint32_t z, total;
+			asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
+			asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
 			const bool fast = i < fast_end && total <= 32;
-			const uint32_t lsbs = __builtin_amdgcn_ubfe(hi, 32u - total, k);
+			const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
 			const uint32_t uf = (z << k) | lsbs;
 			int32_t res = fast ? (int32_t)((uf >> 1) ^ (0u - (uf & 1))) : h.constant;
 			const uint32_t used = fast ? total : 0;
-			r.buf <<= used;
-			r.avail -= used;
+			{
+				// at most one word boundary is crossed (used <= 32)
+				const int32_t left = (int32_t)r.rem - (int32_t)used;
+				const bool cross = left < 0;
+				r.cur = cross ? r.nxt : r.cur;
+				r.nxt = cross ? ring_word : r.nxt;
+				r.wrel += cross ? 1u : 0u;
+				r.rem = (uint32_t)left & 31u;
+			}
 			if (!fast && i < work_end) {
 				if (h.kind >= 2) {
 					if (i < h.order)
@@ -588,7 +592,6 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					}
 				} else
 					res = br_get_signed(r, h.sbps);
-				br_refill(r);
 				if (r.err) {
 					work_end = 0;
 					seg_end = 0;
@@ -633,15 +636,6 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				hist[0] = v;
 			}
 			slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
-			// top the window up to 33..64 bits
-			{
-				const bool c = r.avail <= 32;
-				const uint64_t add = (uint64_t)(c ? r.nxt : 0u) << ((32 - r.avail) & 63);
-				r.buf |= add;
-				r.avail += c ? 32u : 0u;
-				r.nxt = c ? ring_word : r.nxt;
-				r.wrel += c ? 1u : 0u;
-			}
 		}
 		// the block goes out with all 64 threads along memory order
 		const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
