@@ -29,7 +29,7 @@ struct FaFrameCand {
 	uint32_t assignment;
 	uint32_t stream;
 	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch, 4 cut off by the end of input
-	uint32_t lw;             // frames per wave in k_dec_frames and per group in the scratch planes (power of two <= 64)
+	uint32_t reserved;   // keeps the row the size and layout of flacamd_frame_info
 };
 
 void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
