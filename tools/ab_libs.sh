@@ -9,7 +9,7 @@ run() {
 import json, sys
 r = json.loads(open("gpurun_out/ab/%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
 k = r["roofline"]["kernel_ms"]
-print("%-24s encode %.4f ms  %s  decode %.3f ms" % (sys.argv[1], r["ms_per_step"], " ".join("%s=%.4f" % (n, v) for n, v in k.items() if v > 0.02), r["decode"]["ms_per_step"]))
+print("%-24s encode %.4f ms  %s  decode %.3f ms" % (sys.argv[1], r["ms_per_step"], " ".join("%s=%.4f" % (n, v) for n, v in k.items() if v > 0.02), r["decode"]["ms_per_step"]), "exact" if r["decode"]["bit_exact_vs_input"] and r["decode"]["bad_frames"] == 0 else "DECODE WRONG")
 PY
 }
 run default
