@@ -398,6 +398,93 @@ __device__ __forceinline__ void lpc_pred16_dot2(const int32_t (&P)[HIST + FA_CHU
 	}
 }
 
+// The prediction for samples wider than 16 bits, still two taps per instruction: a sample is split
+// as s = sh * 2^12 + sl with sl its low 12 bits (unsigned) and sh = s >> 12 (signed), both of which
+// fit a signed 16-bit lane, so that  sum q s = (sum q sh) * 2^12 + (sum q sl) = A * 2^12 + B  with A
+// and B each one chain of v_dot2_i32_i16.  Ph[k] / Pl[k] hold sh / sl of samples (16 t - HIST + k)
+// and (.. + k + 1) in their low and high halves; qp as for lpc_pred16_dot2.  The caller turns the
+// candidate's arithmetic into three shift counts, pred = ((A << sa) + (B >> sb)) >> sc:
+//   wrapping 32-bit sum (lpc.c:265)       sa = 12, sb = 0, sc = shift:  ((A << 12) + B) is the
+//                                          sum modulo 2^32 whether or not A and B wrapped
+//   64-bit sum (lpc.c:531), shift <= 12    sa = 12 - shift, sb = shift, sc = 0:  A 2^12 is a multiple
+//                                          of 2^shift, so floor(sum / 2^shift) = A 2^(12-shift) +
+//                                          floor(B / 2^shift), and truncation to 32 bits commutes
+//                                          with the addition
+//   64-bit sum, shift > 12                 sa = 0, sb = 12, sc = shift - 12:  the low 12 bits of B
+//                                          cannot carry, so floor(sum / 2^shift) =
+//                                          floor((A + floor(B / 2^12)) / 2^(shift-12))
+// The last two need A and B (and A + (B >> 12)) to be exact in 32 bits, which the caller checks from
+// the sum of the coefficients' magnitudes (fa_split_exact).
+template <int HIST, int MAXORDER, typename Q>
+__device__ __forceinline__ void lpc_pred16_split(const int32_t (&Ph)[HIST + FA_CHUNK - 1], const int32_t (&Pl)[HIST + FA_CHUNK - 1], const Q &qp,
+                                                 uint32_t order, uint32_t sa, uint32_t sb, uint32_t sc, int32_t (&pred)[FA_CHUNK])
+{
+	int32_t A[FA_CHUNK], Bl[FA_CHUNK];
+	if (order == 0) {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			pred[i] = 0;
+		return;
+	}
+	{
+		const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[0]);
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++) {
+			asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(A[i]) : "v"(Ph[HIST + i - 2]), "s"(qv));
+			asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(Bl[i]) : "v"(Pl[HIST + i - 2]), "s"(qv));
+		}
+	}
+#pragma unroll
+	for (int jj = 1; jj < (MAXORDER + 1) / 2; jj++) {
+		if ((uint32_t)(2 * jj) < order) {
+			const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[jj]);
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++) {
+				A[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, Ph[HIST + i - 2 - 2 * jj]), __builtin_bit_cast(fa_short2, qv), A[i], false);
+				Bl[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, Pl[HIST + i - 2 - 2 * jj]), __builtin_bit_cast(fa_short2, qv), Bl[i], false);
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++)
+		pred[i] = (int32_t)(((uint32_t)A[i] << sa) + (uint32_t)(Bl[i] >> sb)) >> sc;
+}
+
+// Whether lpc_pred16_split is exact for a candidate that needs the 64-bit sum: sumq = sum |q[j]|,
+// sbps = bits per sample of the signal.  |B| <= sumq * 4095, |A| <= sumq * 2^max(sbps-13, 0), and
+// A + (B >> 12) must fit as well.
+__device__ __forceinline__ bool fa_split_exact(uint64_t sumq, uint32_t sbps)
+{
+	const uint32_t hb = sbps > 13 ? sbps - 13 : 0;
+	return sumq <= 524415u && (sumq << hb) + (1u << 19) < (1ull << 31);
+}
+
+// The 64-bit prediction (lpc.c:531) spelled out tap by tap, for the candidates the two-taps paths
+// cannot do exactly.  getd(k) returns sample (16 t - HIST + k) of the window; qp as above.  Four
+// samples at a time, so that it adds little to the register budget of the kernel around it: it is
+// there for correctness (coefficient sets that large do not come out of a real signal), not speed.
+template <int HIST, int MAXORDER, typename GetD, typename Q>
+__device__ __forceinline__ void lpc_pred16_exact64(GetD getd, const Q &qp, uint32_t order, int shift, int32_t (&pred)[FA_CHUNK])
+{
+#pragma unroll
+	for (int blk = 0; blk < FA_CHUNK / 4; blk++) {
+		int64_t sum[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int j = 0; j < MAXORDER; j++) {
+			if ((uint32_t)j < order) {
+				const int32_t qw = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[j >> 1]);
+				const int64_t qj = (j & 1) ? (int64_t)(int16_t)(qw & 0xffff) : (int64_t)(qw >> 16);
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					sum[i] += qj * (int64_t)getd(HIST + blk * 4 + i - 1 - j);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+			pred[blk * 4 + i] = (int32_t)(sum[i] >> shift);
+	}
+}
+
 // NARROW: the caller knows every candidate of the stream is MODE 0 (see fa_narrow_only)
 template <int HIST, bool NARROW, typename Q>
 __device__ __forceinline__ void lpc_pred16_any(const int32_t (&d)[HIST + FA_CHUNK], const Q &q, uint32_t order, int shift, int mode,

@@ -135,11 +135,20 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 
 // PAIRS: the PCM is 16-bit stereo read as one 32-bit word per wide sample (a compile-time fact
 // here, so that the other sample formats' code does not weigh on register allocation)
-// DOT2: every signal this launch covers fits 16 bits, so the two-taps-per-instruction residual is
-// the only one compiled in; otherwise only the tap-at-a-time one is.  A launch covers the signals
-// listed in sig_list (four bits each, nsel of them) of every frame.
-template <int HIST, bool NARROW, bool PAIRS, bool DOT2>
-__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SEARCH_WAVES, SEARCH_WAVES)))
+// RES: which residual arithmetic is compiled in.  SR_RES_DOT2: every signal this launch covers fits
+// 16 bits, two taps per v_dot2_i32_i16.  SR_RES_TAPS: samples of up to 24 bits and 32-bit sums only
+// (NARROW streams), a tap per v_mad_i32_i24.  SR_RES_SPLIT: anything wider, samples split into two
+// 16-bit halves, two chains of v_dot2_i32_i16.  The two dot2 forms carry a slow exact path for the
+// candidates whose 64-bit sum they cannot guarantee.  A launch covers the signals listed in sig_list
+// (four bits each, nsel of them) of every frame.
+#define SR_RES_TAPS 0
+#define SR_RES_DOT2 1
+#define SR_RES_SPLIT 2
+// Waves per SIMD = workgroups per CU, which sets the register budget (512 / waves).  The split form
+// keeps both halves of the sample window in registers: 168 registers at order <= 12, 256 beyond.
+#define SR_WAVES(H, R) ((R) == SR_RES_SPLIT ? ((H) > 12 ? 2 : 3) : SEARCH_WAVES)
+template <int HIST, bool NARROW, bool PAIRS, int RES>
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SR_WAVES(HIST, RES), SR_WAVES(HIST, RES))))
 void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans,
               uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps, unsigned long long sig_list, uint32_t nsel)
 {
@@ -358,12 +367,27 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			for (uint32_t j = 0; j < c.order; j++)
 				sumq += abs32(coef(g, j));
 			const uint64_t bound = (1ull << (sbps - 1)) + ((sumq << (sbps - 1)) >> c.shift) + 1;
-			const uint32_t fast = (c.mode == 0 && bound < (1ull << 27)) ? 1u : 0u;
+			// (a sum that wraps in 32 bits stays below 2^(31 - shift), which the bound covers too)
+			const uint32_t fast = ((RES != SR_RES_TAPS || c.mode == 0) && bound < (1ull << 27)) ? 1u : 0u;
 			c.fast = fast;
+			uint32_t slow = 0, sh = (uint32_t)c.shift;
+			if (RES == SR_RES_DOT2) {
+				// one wrapping 32-bit chain: exact for the 64-bit candidates while no sum can reach 2^31
+				slow = (c.mode == 2 && (sumq << (sbps - 1)) >= (1ull << 31)) ? 1u : 0u;
+			} else if (RES == SR_RES_SPLIT) {
+				const uint32_t shf = (uint32_t)c.shift;
+				if (c.mode != 2)
+					sh = 12u | (shf << 16);
+				else if (shf <= 12)
+					sh = (12u - shf) | (shf << 8);
+				else
+					sh = (12u << 8) | ((shf - 12u) << 16);
+				slow = (c.mode == 2 && !fa_split_exact(sumq, sbps)) ? 1u : 0u;
+			}
 			gp[4 * g] = c.order;
-			gp[4 * g + 1] = (uint32_t)c.shift;
+			gp[4 * g + 1] = sh;
 			gp[4 * g + 2] = c.psize;
-			gp[4 * g + 3] = fast | (c.mode << 1);
+			gp[4 * g + 3] = fast | (c.mode << 1) | (slow << 3) | ((uint32_t)c.shift << 8);
 			gq[4 * g] = c.pmax | (c.pmin << 8) | (c.use32 << 16);
 			gq[4 * g + 1] = c.order;
 			gq[4 * g + 2] = c.seed;
@@ -419,7 +443,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			uint32_t part_psize = 0, part_of_chunk = 0;
 			// the next candidate's parameters and coefficients are fetched from LDS while the current
 			// one is computed; at the loop top they move to scalar registers
-			if (DOT2) {
+			if (RES == SR_RES_DOT2) {
 				// samples and coefficients fit 16 bits: two taps per instruction
 				int32_t Pk[HIST + FA_CHUNK - 1];
 #pragma unroll
@@ -438,7 +462,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
 					const int shift = (int)__builtin_amdgcn_readfirstlane(nxp[1]);
 					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
-					const uint32_t fast = __builtin_amdgcn_readfirstlane(nxp[3]) & 1u;
+					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
+					const uint32_t fast = flags & 1u;
 					int32_t qs[NQP];
 #pragma unroll
 					for (int k = 0; k < NQP; k++)
@@ -452,7 +477,62 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 							nxq[k] = cqp[(g + 1) * NQP + k];
 					}
 					int32_t pred[FA_CHUNK];
-					lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
+					if (!NARROW && (flags & 8u))
+						lpc_pred16_exact64<HIST, MAXORDER>([&](int k) -> int32_t { return (int32_t)(int16_t)(Pk[k] & 0xffff); }, qs, order, shift, pred);
+					else
+						lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
+					if (psize != part_psize) {
+						part_psize = psize;
+						part_of_chunk = base / psize;
+					}
+					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
+					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
+				}
+			} else if (RES == SR_RES_SPLIT) {
+				// wider samples in two 16-bit halves: two chains of two taps per instruction
+				int32_t Ph[HIST + FA_CHUNK - 1], Pl[HIST + FA_CHUNK - 1];
+#pragma unroll
+				for (int k = 0; k < HIST + FA_CHUNK - 1; k++) {
+					Ph[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)(d[k + 1] >> 12), (uint32_t)(d[k] >> 12), 0x05040100u);
+					Pl[k] = (int32_t)(((uint32_t)d[k] & 0xfffu) | (((uint32_t)d[k + 1] & 0xfffu) << 16));
+				}
+				uint32_t nxp[4];
+				int32_t nxq[NQP];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					nxp[k] = gp[k];
+#pragma unroll
+				for (int k = 0; k < NQP; k++)
+					nxq[k] = cqp[k];
+#pragma nounroll
+				for (uint32_t g = 0; g < ng; g++) {
+					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
+					const uint32_t shc = __builtin_amdgcn_readfirstlane(nxp[1]);
+					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
+					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
+					const uint32_t fast = flags & 1u;
+					int32_t qs[NQP];
+#pragma unroll
+					for (int k = 0; k < NQP; k++)
+						qs[k] = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxq[k]);
+					if (g + 1 < ng) {
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							nxp[k] = gp[4 * (g + 1) + k];
+#pragma unroll
+						for (int k = 0; k < NQP; k++)
+							nxq[k] = cqp[(g + 1) * NQP + k];
+					}
+					int32_t pred[FA_CHUNK];
+					if (flags & 8u) {
+						// sample k of the window, put together again from its halves
+						// (the taps of the chunk's samples reach window samples 0 .. HIST + 14 only)
+						auto getd = [&](int k) -> int32_t {
+							return (int32_t)(((uint32_t)(int32_t)(int16_t)((uint32_t)Ph[k] & 0xffff) << 12) | ((uint32_t)Pl[k] & 0xfffu));
+						};
+						lpc_pred16_exact64<HIST, MAXORDER>(getd, qs, order, (int)(flags >> 8), pred);
+					} else
+						lpc_pred16_split<HIST, MAXORDER>(Ph, Pl, qs, order, shc & 0xff, (shc >> 8) & 0xff, shc >> 16, pred);
 					if (psize != part_psize) {
 						part_psize = psize;
 						part_of_chunk = base / psize;
@@ -476,7 +556,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
 					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
 					const uint32_t fast = flags & 1u;
-					const int mode = (int)(flags >> 1);
+					const int mode = (int)((flags >> 1) & 3u);
 					int32_t qs[MAXORDER];
 #pragma unroll
 					for (int k = 0; k < MAXORDER; k++)
@@ -801,17 +881,19 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 		else
 			list_taps |= (unsigned long long)sg << (4 * n_taps++);
 	}
-#define SEARCH_LAUNCH1(H, N, PR, D, LIST, NSEL) \
-	hipLaunchKernelGGL((k_search<H, N, PR, D>), dim3(B.nframes * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
+#define SEARCH_LAUNCH1(H, N, PR, R, LIST, NSEL) \
+	hipLaunchKernelGGL((k_search<H, N, PR, R>), dim3(B.nframes * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
 	                   stamps, LIST, NSEL)
+	// the signals too wide for one 16-bit lane: a tap per instruction while 32-bit sums of 24-bit
+	// samples are all the stream can need, the split form otherwise
 #define SEARCH_LAUNCH(H, N) \
 	do { \
 		if (B.pairs) { \
-			if (n_dot2) SEARCH_LAUNCH1(H, N, true, (H >= 12), list_dot2, n_dot2); \
-			if (n_taps) SEARCH_LAUNCH1(H, N, true, false, list_taps, n_taps); \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, true, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, true, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps); \
 		} else { \
-			if (n_dot2) SEARCH_LAUNCH1(H, N, false, (H >= 12), list_dot2, n_dot2); \
-			if (n_taps) SEARCH_LAUNCH1(H, N, false, false, list_taps, n_taps); \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, false, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, false, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps); \
 		} \
 	} while (0)
 	const bool narrow = fa_narrow_only(P);
