@@ -84,6 +84,19 @@ def cpu_baseline(seconds=SECONDS):
     }
 
 
+def launch_ranks(n):
+    """Run this script as n ranks under torch.distributed.run (one per GPU, RCCL rendezvous on
+    127.0.0.1) and return the launcher's exit code; rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +108,13 @@ def main():
     ap.add_argument("--no-stream-api", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) as children
+        # of this process, which has not touched the GPU and never will
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -103,39 +123,58 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU (torch.cuda.is_available() is False)")
+        raise SystemExit("bench.py needs an AMD GPU (torch.cuda.is_available() is False) [rank %d of %d]" % (rank, world))
+    # FLAC_AMD_BENCH_REHEARSE=1: every rank on GPU 0 and the collectives over gloo through host
+    # memory - a rehearsal of the N-rank path on a one-GPU box, not a measurement
+    rehearse = bool(os.environ.get("FLAC_AMD_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs GPU %d, this node shows %d" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    coll_dev = torch.device("cpu") if rehearse else dev
 
     # ---- workload: this rank's shard of the stream, resident in HBM as interleaved int16 ----
-    pcm32 = make_pcm(1234 + 1000 * rank, args.seconds)
-    wide = pcm32.shape[0]
+    # weak scaling: the job is ONE stream of world x 6460 frames cut into contiguous frame ranges;
+    # every block is full except the stream's last one (the 600 s workload ends 160 samples short of
+    # a block), so the ranks' bytes put end to end are a valid stream
     params = flac_amd.preset(LEVEL, CHANNELS, BPS, RATE)
     bs = params.blocksize
-    nframes = (wide + bs - 1) // bs
     from flac_amd import shard
-    # weak scaling: the job is one stream of world x nframes frames, split into contiguous ranges
-    first_frame, owned = shard.frame_range(nframes * world, world, rank)
-    assert owned == nframes
+    wide_one = int(round(args.seconds * RATE))
+    frames_one = (wide_one + bs - 1) // bs
+    stream_wide = (world - 1) * frames_one * bs + wide_one
+    first_frame, first_sample, wide = shard.sample_range(stream_wide, bs, world, rank)
+    nframes = (wide + bs - 1) // bs
+    assert nframes == frames_one and first_frame == rank * frames_one
+    pcm32 = make_pcm(1234 + 1000 * rank, (frames_one * bs + 1) / RATE)[:wide]
+    assert pcm32.shape[0] == wide
+    is_last = rank == world - 1
     pcm_dev = torch.from_numpy(pcm32.astype(np.int16)).to(dev)
     enc = flac_amd.Encoder(params, device=local_rank, max_frames=nframes)
     out_cap = enc.max_output_bytes(nframes)
     out_dev = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     fbytes_dev = torch.zeros(nframes, dtype=torch.int32, device=dev)
     offs_dev = torch.zeros(nframes + 1, dtype=torch.int64, device=dev)
-    totals = torch.zeros(world, dtype=torch.int64, device=dev)
+    totals = torch.zeros(world, dtype=torch.int64, device=coll_dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         enc.encode_device(pcm_dev.data_ptr(), 2, wide, out_dev.data_ptr(), out_cap, fbytes_dev.data_ptr(),
-                          offs_dev.data_ptr(), first_frame=first_frame, is_last=True, stream=stream)
+                          offs_dev.data_ptr(), first_frame=first_frame, is_last=is_last, stream=stream)
         if world > 1:
             # stream offsets of the shards: all-gather of the per-rank byte totals over RCCL
-            dist.all_gather_into_tensor(totals, offs_dev[nframes:nframes + 1])
+            dist.all_gather_into_tensor(totals, offs_dev[nframes:nframes + 1].to(coll_dev))
 
     for _ in range(args.warmup):
         step()
@@ -151,13 +190,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if not os.environ.get("FLAC_AMD_BENCH_NOCHECK"):  # kernel experiments whose output is knowingly wrong
+    status_checked = not os.environ.get("FLAC_AMD_BENCH_NOCHECK")  # kernel experiments whose output is knowingly wrong
+    if status_checked:
         enc.status()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    samples_per_step = wide * CHANNELS * world
+    samples_per_step = stream_wide * CHANNELS
     value = samples_per_step * args.steps / elapsed / 1e6
     flac_bytes = int(offs_dev[nframes].item())
 
@@ -167,7 +207,7 @@ def main():
     nprof = max(3, min(10, args.steps))
     for _ in range(nprof):
         enc.encode_device(pcm_dev.data_ptr(), 2, wide, out_dev.data_ptr(), out_cap, fbytes_dev.data_ptr(),
-                          offs_dev.data_ptr(), first_frame=first_frame, is_last=True, stream=stream)
+                          offs_dev.data_ptr(), first_frame=first_frame, is_last=is_last, stream=stream)
         torch.cuda.synchronize()
         for k, v in enc.stage_ms().items():
             acc[k] = acc.get(k, 0.0) + v / nprof
@@ -187,9 +227,11 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        **({"rehearsal": "all ranks on GPU 0, gloo collectives through host memory: not a measurement"} if rehearse else {}),
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
+        "status_checked": bool(status_checked),
         "config": {
             "workload": "C2: flac -8 (max LPC order 12, tukey(0.5), Rice partition order 0-6), 16-bit/44.1kHz stereo, "
                         "blocksize 4096, %.0f s (%d frames) per GPU, PCM resident in HBM as int16" % (args.seconds, nframes),
@@ -219,9 +261,29 @@ def main():
     if not args.no_decode and hasattr(flac_amd.lib(), "flacamd_decode_streams"):
         try:
             result["decode"] = bench_decode(torch, flac_amd, dev, local_rank, world, dist, out_dev, flac_bytes, wide, bs,
-                                            nframes, args, pcm_dev)
+                                            nframes, args, pcm_dev, stream_wide)
         except Exception as exc:  # the encode line must still be printed
             result["decode"] = {"error": str(exc)}
+
+    # ---- N > 1: the shards put together into the one stream they belong to (output collection,
+    # outside the timed region), which rank 0 then decodes whole: every frame of every rank must
+    # be found, in order, with a good CRC-16 ----
+    if world > 1:
+        whole = shard.gather_stream(out_dev[:flac_bytes])
+        if rank == 0:
+            try:
+                dec = flac_amd.Decoder(CHANNELS, BPS, bs, device=local_rank, max_input_bytes=whole.numel() + 64, max_frames=nframes * world + 16)
+                back = torch.empty(stream_wide * CHANNELS, dtype=torch.int16, device=dev)
+                dec.decode_device(whole.data_ptr(), whole.numel(), [(0, whole.numel(), 0, stream_wide, 0)], back.data_ptr(), 2, stream_wide)
+                frames, got_wide, bad = dec.result()
+                dec.close()
+                result["assembled_stream"] = {"bytes": int(whole.numel()), "frames": frames, "wide_samples": got_wide, "bad_frames": bad,
+                                              "rank0_shard_bit_exact": bool(torch.equal(back[:wide * CHANNELS].view(-1, CHANNELS), pcm_dev)),
+                                              "ok": frames == nframes * world and bad == 0 and got_wide == stream_wide}
+                del back
+            except Exception as exc:
+                result["assembled_stream"] = {"error": str(exc)}
+        del whole
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
     # the gfx950 note prescribes, + WRITE_SIZE); collected by separate runs of this same command
@@ -304,7 +366,7 @@ def bench_stream_api(flac_amd, pcm32, do_md5=True):
                     "write callbacks included; one host thread" % ("MD5, " if do_md5 else "no MD5, ")}
 
 
-def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev):
+def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev, stream_wide):
     dec = flac_amd.Decoder(CHANNELS, BPS, bs, device=local_rank, max_input_bytes=flac_bytes + 64, max_frames=nframes + 16)
     out = torch.zeros(wide * CHANNELS, dtype=torch.int16, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -335,13 +397,13 @@ def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_b
     ms = dec.stage_ms()
     dec.close()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if os.environ.get("FLAC_AMD_BENCH_REHEARSE") else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     alg = flac_bytes + wide * CHANNELS * 2
     dom = max(ms, key=ms.get)
     return {
-        "value": wide * CHANNELS * world * args.steps / elapsed / 1e6,
+        "value": stream_wide * CHANNELS * args.steps / elapsed / 1e6,
         "unit": "MSamples/s",
         "ms_per_step": elapsed / args.steps * 1e3,
         "frames": frames, "bad_frames": bad, "bit_exact_vs_input": exact,

@@ -63,3 +63,60 @@ def stream_offsets(local_bytes: int, group=None, device=None) -> Tuple[int, int,
     dist.all_gather_into_tensor(totals, mine, group=group)
     sizes = [int(x) for x in totals.tolist()]
     return sum(sizes[:rank]), sum(sizes), sizes
+
+
+def gather_stream(local, group=None, dst: int = 0):
+    """Put the ranks' frame bytes together into the one stream they are shards of.
+
+    `local` is this rank's bytes: a 1-D uint8 tensor (on the GPU under RCCL, on the CPU under gloo),
+    or a bytes object.  Every rank calls it; rank `dst` gets the whole stream (same kind as
+    `local`), the others get None.  The sizes travel first (stream_offsets), then one all-gather of
+    the shards padded to the largest one; rank dst cuts the padding out.  This is the output
+    collection step of a sharded encode, the counterpart of the reference handing each frame to its
+    write callback in order (stream_encoder.c:2379-2513): frame f of rank r lands after every frame
+    of ranks 0..r-1.
+    """
+    import torch
+    import torch.distributed as dist
+
+    as_bytes = isinstance(local, (bytes, bytearray, memoryview))
+    t = torch.frombuffer(bytearray(local), dtype=torch.uint8) if as_bytes else local
+    if t.dtype != torch.uint8 or t.dim() != 1:
+        raise ValueError("gather_stream wants a 1-D uint8 tensor or bytes")
+    if not (dist.is_available() and dist.is_initialized()):
+        return bytes(local) if as_bytes else t
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    # a CPU-only backend (gloo) moves the bytes through host memory
+    home = t.device
+    via = home if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    _off, _total, sizes = stream_offsets(t.numel(), group=group, device=via)
+    width = max(max(sizes), 1)
+    padded = torch.zeros(width, dtype=torch.uint8, device=via)
+    padded[:t.numel()] = t.to(via)
+    everything = torch.empty(world * width, dtype=torch.uint8, device=via)
+    dist.all_gather_into_tensor(everything, padded, group=group)
+    if rank != dst:
+        return None
+    stream = torch.cat([everything[r * width:r * width + sizes[r]] for r in range(world)]).to(home)
+    return stream.cpu().numpy().tobytes() if as_bytes else stream
+
+
+def deal_streams(nstreams: int, world: int, rank: int) -> List[int]:
+    """Batch decode is replica-style: stream i goes to rank i mod world, nothing is exchanged
+    (each stream is a whole file with its own frame numbering, stream_decoder.c:1941-2113 keeps
+    no state between streams).  Returns the stream indices `rank` decodes, in order."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank %d of %d" % (rank, world))
+    return list(range(rank, nstreams, world))
+
+
+def undeal(per_rank: List[list]) -> list:
+    """Inverse of deal_streams for results: per_rank[r][k] is the result of stream r + k * world."""
+    world = len(per_rank)
+    total = sum(len(x) for x in per_rank)
+    out = [None] * total
+    for r, items in enumerate(per_rank):
+        for k, item in enumerate(items):
+            out[r + k * world] = item
+    return out

@@ -49,6 +49,20 @@ def worker(rank, world, port, case_name, out_path):
             f.seek(offset)
             f.write(blob)
         dist.barrier()
+        # the same through the product's own collection step: rank 0 receives the whole stream
+        whole = shard.gather_stream(blob)
+        if rank == 0:
+            assert len(whole) == total
+            with open(out_path + ".gathered", "wb") as f:
+                f.write(whole)
+        else:
+            assert whole is None
+        import torch
+        as_tensor = shard.gather_stream(torch.frombuffer(bytearray(blob), dtype=torch.uint8) if blob else torch.zeros(0, dtype=torch.uint8), dst=1)
+        if rank == 1:
+            assert as_tensor.numpy().tobytes() == open(out_path + ".gathered", "rb").read()
+        else:
+            assert as_tensor is None
     finally:
         dist.destroy_process_group()
 
@@ -61,6 +75,48 @@ def test_two_ranks_assemble_the_reference_stream(tmp_path, case_name):
     case = next(c for c in golden_util.load_index() if c["name"] == case_name)
     _pcm, _meta, frames = golden_util.load_case(case)
     assert open(out, "rb").read() == b"".join(frames)
+    assert open(out + ".gathered", "rb").read() == b"".join(frames)
+
+
+def deal_worker(rank, world, port, names, out_dir):
+    """Batch decode, replica-style: each rank decodes the streams dealt to it (with the CPU oracle
+    here, with the HIP decoder on GPUs), nothing is exchanged; the parent puts the results back in
+    stream order with shard.undeal."""
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    from flac_amd import shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cases = {c["name"]: c for c in golden_util.load_index()}
+        for k, i in enumerate(shard.deal_streams(len(names), world, rank)):
+            case = cases[names[i]]
+            pcm, _meta, frames = golden_util.load_case(case)
+            n, got, _nf = O.decode_frames(b"".join(frames), case["channels"], case["bps"], case["rate"], pcm.shape[0])
+            assert n == pcm.shape[0]
+            np.save(os.path.join(out_dir, "r%d_%d.npy" % (rank, k)), got)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_decode_a_dealt_batch(tmp_path):
+    import torch.multiprocessing as mp
+
+    from flac_amd import shard
+    names = ["s16_l8", "s16_l5_bs256", "s16_l1_loose", "s24_l8", "m16_l8"]
+    have = {c["name"] for c in golden_util.load_index()}
+    names = [n for n in names if n in have]
+    assert len(names) >= 3
+    mp.spawn(deal_worker, args=(2, free_port(), names, str(tmp_path)), nprocs=2, join=True)
+    per_rank = [[np.load(str(tmp_path / ("r%d_%d.npy" % (r, k)))) for k in range(len(shard.deal_streams(len(names), 2, r)))] for r in range(2)]
+    cases = {c["name"]: c for c in golden_util.load_index()}
+    for name, got in zip(names, shard.undeal(per_rank)):
+        pcm, _meta, _frames = golden_util.load_case(cases[name])
+        assert np.array_equal(got, pcm), name
 
 
 def test_frame_ranges_cover_and_align():
@@ -87,3 +143,15 @@ def test_frame_ranges_cover_and_align():
 def test_stream_offsets_single_process():
     from flac_amd import shard
     assert shard.stream_offsets(123) == (0, 123, [123])
+    assert shard.gather_stream(b"abc") == b"abc"
+
+
+def test_deal_streams_round_robin():
+    from flac_amd import shard
+    for n in (0, 1, 7, 10000):
+        for world in (1, 2, 8):
+            dealt = [shard.deal_streams(n, world, r) for r in range(world)]
+            assert shard.undeal(dealt) == list(range(n))
+            assert max(len(d) for d in dealt) - min(len(d) for d in dealt) <= 1
+    with pytest.raises(ValueError):
+        shard.deal_streams(4, 2, 2)
