@@ -106,6 +106,53 @@ static size_t slot_bytes_for(const flacamd_encode_params &p)
 	return (s + 63) / 64 * 64 + 64;
 }
 
+// The kernels' view of resolved settings.
+static void fill_kernel_params(const flacamd_encode_params &p, FaEncParams &P)
+{
+	P.channels = p.channels;
+	P.bps = p.bits_per_sample;
+	P.sample_rate = p.sample_rate;
+	P.blocksize = p.blocksize;
+	P.do_ms = p.do_mid_side_stereo ? 1 : 0;
+	P.loose_ms = p.loose_mid_side_stereo ? 1 : 0;
+	P.nsignals = p.channels + (P.do_ms ? 2 : 0);
+	// stream_encoder.c:871
+	P.loose_frames = (uint32_t)((double)p.sample_rate * 0.4 / (double)p.blocksize + 0.5);
+	if (P.loose_frames == 0)
+		P.loose_frames = 1;
+	P.max_lpc_order = p.max_lpc_order;
+	P.qlp_precision = p.qlp_coeff_precision;
+	P.prec_search = p.do_qlp_coeff_prec_search ? 1 : 0;
+	P.exhaustive = p.do_exhaustive_model_search ? 1 : 0;
+	P.min_po = p.min_residual_partition_order;
+	P.max_po = p.max_residual_partition_order;
+	P.disable_constant = p.disable_constant_subframes ? 1 : 0;
+	P.disable_fixed = p.disable_fixed_subframes ? 1 : 0;
+	P.disable_verbatim = p.disable_verbatim_subframes ? 1 : 0;
+	P.napod = p.num_apodizations;
+	P.rice_limit = p.bits_per_sample > 16 ? 31 : 15;  // stream_encoder.c:3195
+	uint32_t il = 0;
+	for (uint32_t b = p.blocksize; b >>= 1;)
+		il++;
+	P.wide_fixed = (p.bits_per_sample + il + 1 > 30) ? 1 : 0;  // stream_encoder.c:887
+	P.nprec = P.prec_search ? 11 : 1;
+	P.ncand = P.napod * P.max_lpc_order * P.nprec;
+	P.slot_bytes = (uint32_t)slot_bytes_for(p);
+}
+
+// what counts for the device limit is the order a full block can reach: the setting, capped by how
+// often the blocksize halves evenly (stream_encoder.c:2929-2936)
+static int check_partition_reach(const flacamd_encode_params &p)
+{
+	uint32_t reach = 0;
+	while (reach < p.max_residual_partition_order && !((p.blocksize >> reach) & 1))
+		reach++;
+	if (reach > FLACAMD_MAX_PARTITION_ORDER)
+		return fa_fail(FLACAMD_E_UNSUPPORTED, "Rice partition order %u (blocksize %u, max order setting %u) exceeds the device limit %d", reach,
+		               p.blocksize, p.max_residual_partition_order, FLACAMD_MAX_PARTITION_ORDER);
+	return FLACAMD_OK;
+}
+
 extern "C" size_t flacamd_encoder_max_output_bytes(const flacamd_encoder *e, uint32_t nframes)
 {
 	return e ? (size_t)e->P.slot_bytes * nframes : 0;
@@ -147,16 +194,9 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	int rc = flacamd_params_resolve(&p);
 	if (rc)
 		return rc;
-	{
-		// what counts is the order a full block can reach: the setting, capped by how often the
-		// blocksize halves evenly (stream_encoder.c:2929-2936)
-		uint32_t reach = 0;
-		while (reach < p.max_residual_partition_order && !((p.blocksize >> reach) & 1))
-			reach++;
-		if (reach > FLACAMD_MAX_PARTITION_ORDER)
-			return fa_fail(FLACAMD_E_UNSUPPORTED, "Rice partition order %u (blocksize %u, max order setting %u) exceeds the device limit %d", reach,
-			               p.blocksize, p.max_residual_partition_order, FLACAMD_MAX_PARTITION_ORDER);
-	}
+	rc = check_partition_reach(p);
+	if (rc)
+		return rc;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		return fa_fail(FLACAMD_E_DEVICE, "no HIP device available: the FLAC engine needs an AMD GPU");
@@ -172,35 +212,7 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	e->device = device;
 	e->max_frames = max_frames;
 	FaEncParams &P = e->P;
-	P.channels = p.channels;
-	P.bps = p.bits_per_sample;
-	P.sample_rate = p.sample_rate;
-	P.blocksize = p.blocksize;
-	P.do_ms = p.do_mid_side_stereo ? 1 : 0;
-	P.loose_ms = p.loose_mid_side_stereo ? 1 : 0;
-	P.nsignals = p.channels + (P.do_ms ? 2 : 0);
-	// stream_encoder.c:871
-	P.loose_frames = (uint32_t)((double)p.sample_rate * 0.4 / (double)p.blocksize + 0.5);
-	if (P.loose_frames == 0)
-		P.loose_frames = 1;
-	P.max_lpc_order = p.max_lpc_order;
-	P.qlp_precision = p.qlp_coeff_precision;
-	P.prec_search = p.do_qlp_coeff_prec_search ? 1 : 0;
-	P.exhaustive = p.do_exhaustive_model_search ? 1 : 0;
-	P.min_po = p.min_residual_partition_order;
-	P.max_po = p.max_residual_partition_order;
-	P.disable_constant = p.disable_constant_subframes ? 1 : 0;
-	P.disable_fixed = p.disable_fixed_subframes ? 1 : 0;
-	P.disable_verbatim = p.disable_verbatim_subframes ? 1 : 0;
-	P.napod = p.num_apodizations;
-	P.rice_limit = p.bits_per_sample > 16 ? 31 : 15;  // stream_encoder.c:3195
-	uint32_t il = 0;
-	for (uint32_t b = p.blocksize; b >>= 1;)
-		il++;
-	P.wide_fixed = (p.bits_per_sample + il + 1 > 30) ? 1 : 0;  // stream_encoder.c:887
-	P.nprec = P.prec_search ? 11 : 1;
-	P.ncand = P.napod * P.max_lpc_order * P.nprec;
-	P.slot_bytes = (uint32_t)slot_bytes_for(p);
+	fill_kernel_params(p, P);
 
 	const size_t F = max_frames, S = P.nsignals;
 #define ALLOC(ptr, bytes) \
@@ -247,13 +259,19 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	uint16_t t16[256], pow16[32];
 	uint8_t t8[256];
 	make_crc_tables(t16, pow16, t8);
-	fa_upload_crc_tables(t16, pow16, t8);
+	if (hipError_t up = fa_upload_crc_tables(t16, pow16, t8); up != hipSuccess) {
+		flacamd_encoder_destroy(e);
+		return fa_fail(FLACAMD_E_DEVICE, "CRC table upload failed: %s", hipGetErrorString(up));
+	}
 	for (int i = 0; i <= FLACAMD_ENC_STAGES; i++)
 		if (hipEventCreate(&e->ev[i]) != hipSuccess) {
 			flacamd_encoder_destroy(e);
 			return fa_fail(FLACAMD_E_DEVICE, "hipEventCreate failed");
 		}
-	HIP_TRY(hipDeviceSynchronize());
+	if (hipError_t sy = hipDeviceSynchronize(); sy != hipSuccess) {
+		flacamd_encoder_destroy(e);
+		return fa_fail(FLACAMD_E_DEVICE, "hipDeviceSynchronize failed: %s", hipGetErrorString(sy));
+	}
 	*out = e;
 	return FLACAMD_OK;
 }
@@ -283,15 +301,27 @@ extern "C" int flacamd_encoder_stage_ms(flacamd_encoder *e, float ms[FLACAMD_ENC
 	return FLACAMD_OK;
 }
 
-extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, uint32_t sample_bytes, uint64_t wide_samples,
-                                     uint32_t first_frame, int is_last, uint32_t *loose_state, void *out_dev, size_t out_capacity,
-                                     uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev, uint32_t *nframes_out, void *stream)
+// The device buffers one batch works in, whoever owns them.
+struct EncWork {
+	const float *windows;
+	FaSubStat *stats;
+	float *autoc;
+	FaLpcCand *cands;
+	int32_t *coefs;
+	FaPlan *plans;
+	uint32_t *assign;
+	uint32_t *slots;
+	uint32_t *errflag;    // [0] device error bits, [1] loose mid/side state out
+};
+
+// Argument checks shared by the batch entry points; fills B and *nf.
+static int check_batch(const FaEncParams &P, const void *pcm_dev, const void *out_dev, uint32_t sample_bytes, uint64_t wide_samples,
+                       uint32_t first_frame, int is_last, const uint32_t *loose_state, FaBatch &B, uint64_t *nf_out)
 {
-	if (!e || !pcm_dev || !out_dev)
-		return fa_fail(FLACAMD_E_INVALID, "flacamd_encode_frames: null argument");
+	if (!pcm_dev || !out_dev)
+		return fa_fail(FLACAMD_E_INVALID, "encode: null argument");
 	if (sample_bytes < 2 || sample_bytes > 4)
 		return fa_fail(FLACAMD_E_INVALID, "sample_bytes must be 2, 3 or 4");
-	const FaEncParams &P = e->P;
 	if (sample_bytes * 8 < P.bps)
 		return fa_fail(FLACAMD_E_INVALID, "%u-byte samples cannot hold %u bits", sample_bytes, P.bps);
 	const uint64_t full = wide_samples / P.blocksize;
@@ -299,17 +329,9 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	if (rem && !is_last)
 		return fa_fail(FLACAMD_E_INVALID, "only the last batch may end in a short block (%u samples left over)", rem);
 	const uint64_t nf = full + (rem ? 1 : 0);
-	if (nframes_out)
-		*nframes_out = (uint32_t)nf;
-	if (nf == 0)
-		return FLACAMD_OK;
-	if (nf > e->max_frames)
-		return fa_fail(FLACAMD_E_INVALID, "batch of %llu frames exceeds the encoder's capacity of %u", (unsigned long long)nf, e->max_frames);
+	*nf_out = nf;
 	if ((uint64_t)first_frame + nf > 0x7fffffffull)
 		return fa_fail(FLACAMD_E_INVALID, "frame number exceeds 31 bits");
-	HIP_TRY(hipSetDevice(e->device));
-	hipStream_t st = (hipStream_t)stream;
-	FaBatch B;
 	B.wide_samples = wide_samples;
 	B.nframes = (uint32_t)nf;
 	B.first_frame = first_frame;
@@ -317,41 +339,84 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	B.loose_carry = loose_state ? *loose_state : 0;
 	B.pairs = (sample_bytes == 2 && P.channels == 2 && ((uintptr_t)pcm_dev & 3) == 0) ? 1u : 0u;
 	B.pad = 0;
-	uint32_t *fb = frame_bytes_dev ? frame_bytes_dev : e->frame_bytes;
-	uint64_t *fo = frame_offsets_dev ? frame_offsets_dev : e->offsets;
-	const bool prof = e->profiling != 0;
+	return FLACAMD_OK;
+}
+
+// The kernel sequence of one batch.  ev: FLACAMD_ENC_STAGES + 1 events to record between the
+// stages, or null.
+static int run_batch(const FaEncParams &P, const FaBatch &B, const EncWork &W, const void *pcm_dev, void *out_dev, size_t out_capacity,
+                     uint32_t *fb, uint64_t *fo, hipStream_t st, hipEvent_t *ev)
+{
 	int evi = 0;
 #define STAGE_MARK() \
 	do { \
-		if (prof) \
-			HIP_TRY(hipEventRecord(e->ev[evi++], st)); \
+		if (ev) \
+			HIP_TRY(hipEventRecord(ev[evi++], st)); \
 	} while (0)
+	const char *stamps_env = getenv("FLAC_AMD_STAMPS");
 	STAGE_MARK();
-	fa_launch_analyze(P, B, pcm_dev, e->stats, st);
-	STAGE_MARK();
-	if (P.max_lpc_order > 0)
-		fa_launch_autoc(P, B, pcm_dev, e->stats, e->windows, e->autoc, st);
+	fa_launch_analyze(P, B, pcm_dev, W.stats, st);
 	STAGE_MARK();
 	if (P.max_lpc_order > 0)
-		fa_launch_lpc(P, B, e->stats, e->autoc, e->cands, e->coefs, st);
+		fa_launch_autoc(P, B, pcm_dev, W.stats, W.windows, W.autoc, st);
+	STAGE_MARK();
+	if (P.max_lpc_order > 0)
+		fa_launch_lpc(P, B, W.stats, W.autoc, W.cands, W.coefs, st);
 	STAGE_MARK();
 	// FLAC_AMD_STAMPS: per-workgroup cycle stamps of k_search land in the (by now consumed) autocorrelation buffer
-	fa_launch_search(P, B, pcm_dev, e->stats, e->cands, e->coefs, e->plans, (getenv("FLAC_AMD_STAMPS") && strcmp(getenv("FLAC_AMD_STAMPS"), "pack")) ? (unsigned long long *)e->autoc : nullptr, st);
+	fa_launch_search(P, B, pcm_dev, W.stats, W.cands, W.coefs, W.plans, (stamps_env && strcmp(stamps_env, "pack")) ? (unsigned long long *)W.autoc : nullptr, st);
 	STAGE_MARK();
-	fa_launch_decide(P, B, e->plans, e->assign, e->errflag + 1, st);
+	fa_launch_decide(P, B, W.plans, W.assign, W.errflag + 1, st);
 	STAGE_MARK();
 	// FLAC_AMD_STAMPS=pack: the same for k_pack (the candidate buffer is consumed by then)
-	fa_launch_pack(P, B, pcm_dev, e->stats, e->plans, e->assign, e->slots, fb, e->errflag,
-	               (getenv("FLAC_AMD_STAMPS") && !strcmp(getenv("FLAC_AMD_STAMPS"), "pack")) ? (unsigned long long *)e->autoc : nullptr, st);
+	fa_launch_pack(P, B, pcm_dev, W.stats, W.plans, W.assign, W.slots, fb, W.errflag,
+	               (stamps_env && !strcmp(stamps_env, "pack")) ? (unsigned long long *)W.autoc : nullptr, st);
 	STAGE_MARK();
 	fa_launch_scan(fb, B.nframes, fo, st);
 	STAGE_MARK();
-	fa_launch_compact(P, B, e->slots, fb, fo, (uint8_t *)out_dev, out_capacity, e->errflag, st);
+	fa_launch_compact(P, B, W.slots, fb, fo, (uint8_t *)out_dev, out_capacity, W.errflag, st);
 	STAGE_MARK();
 #undef STAGE_MARK
-	if (prof)
-		e->have_times = 1;
 	HIP_TRY(hipGetLastError());
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, uint32_t sample_bytes, uint64_t wide_samples,
+                                     uint32_t first_frame, int is_last, uint32_t *loose_state, void *out_dev, size_t out_capacity,
+                                     uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev, uint32_t *nframes_out, void *stream)
+{
+	if (!e)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_encode_frames: null argument");
+	const FaEncParams &P = e->P;
+	FaBatch B;
+	uint64_t nf = 0;
+	int rc = check_batch(P, pcm_dev, out_dev, sample_bytes, wide_samples, first_frame, is_last, loose_state, B, &nf);
+	if (rc)
+		return rc;
+	if (nframes_out)
+		*nframes_out = (uint32_t)nf;
+	if (nf == 0)
+		return FLACAMD_OK;
+	if (nf > e->max_frames)
+		return fa_fail(FLACAMD_E_INVALID, "batch of %llu frames exceeds the encoder's capacity of %u", (unsigned long long)nf, e->max_frames);
+	HIP_TRY(hipSetDevice(e->device));
+	hipStream_t st = (hipStream_t)stream;
+	EncWork W;
+	W.windows = e->windows;
+	W.stats = e->stats;
+	W.autoc = e->autoc;
+	W.cands = e->cands;
+	W.coefs = e->coefs;
+	W.plans = e->plans;
+	W.assign = e->assign;
+	W.slots = e->slots;
+	W.errflag = e->errflag;
+	rc = run_batch(P, B, W, pcm_dev, out_dev, out_capacity, frame_bytes_dev ? frame_bytes_dev : e->frame_bytes,
+	               frame_offsets_dev ? frame_offsets_dev : e->offsets, st, e->profiling ? e->ev : nullptr);
+	if (rc)
+		return rc;
+	if (e->profiling)
+		e->have_times = 1;
 	if (loose_state && P.loose_ms) {
 		// the next batch needs this batch's last decision
 		HIP_TRY(hipMemcpyAsync(loose_state, e->errflag + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

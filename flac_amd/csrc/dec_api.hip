@@ -146,13 +146,19 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 		pow16[j] = (uint16_t)p;
 		p = mul(p, p);
 	}
-	fa_dec_upload_tables(t16, pow16, t8);
+	if (hipError_t up = fa_dec_upload_tables(t16, pow16, t8); up != hipSuccess) {
+		flacamd_decoder_destroy(d);
+		return fa_fail(FLACAMD_E_DEVICE, "CRC table upload failed: %s", hipGetErrorString(up));
+	}
 	for (int i = 0; i <= FLACAMD_DEC_STAGES; i++)
 		if (hipEventCreate(&d->ev[i]) != hipSuccess) {
 			flacamd_decoder_destroy(d);
 			return fa_fail(FLACAMD_E_DEVICE, "hipEventCreate failed");
 		}
-	HIP_TRY(hipDeviceSynchronize());
+	if (hipError_t sy = hipDeviceSynchronize(); sy != hipSuccess) {
+		flacamd_decoder_destroy(d);
+		return fa_fail(FLACAMD_E_DEVICE, "hipDeviceSynchronize failed: %s", hipGetErrorString(sy));
+	}
 	*out = d;
 	return FLACAMD_OK;
 }
@@ -183,6 +189,14 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	}
 	HIP_TRY(hipSetDevice(d->device));
 	hipStream_t st = (hipStream_t)stream;
+	if (flac_bytes == 0) {
+		// nothing to look through: no frames, the output cleared like that of any other input
+		HIP_TRY(hipMemsetAsync(d->ncand, 0, 16, st));
+		HIP_TRY(hipMemsetAsync(d->result, 0, 32, st));
+		HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, (size_t)out_capacity_wide * d->channels * out_sample_bytes, st));
+		d->last_stream = st;
+		return FLACAMD_OK;
+	}
 	static_assert(sizeof(FaStream) == sizeof(flacamd_stream_desc), "stream descriptor layout");
 	HIP_TRY(hipMemcpyAsync(d->streams, streams_host, sizeof(FaStream) * nstreams, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(d->ncand, 0, 16, st));

@@ -32,7 +32,7 @@ struct FaFrameCand {
 	uint32_t reserved;   // keeps the row the size and layout of flacamd_frame_info
 };
 
-void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
+hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
 void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
                         FaFrameCand *cands, uint32_t *ncand, hipStream_t st);

@@ -38,11 +38,15 @@ __constant__ uint16_t c_dec_crc16x4[4][256];  // table k: CRC-16 of a byte follo
 __constant__ uint16_t c_dec_runpow[4][64];
 __constant__ uint16_t c_dec_segpow[4];
 
-void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
+hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
 {
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16), t16, 512);
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_pow16), pow16, 64);
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc8), t8, 256);
+	hipError_t rc = hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16), t16, 512);
+	if (rc == hipSuccess)
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(c_dec_pow16), pow16, 64);
+	if (rc == hipSuccess)
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc8), t8, 256);
+	if (rc != hipSuccess)
+		return rc;
 	static uint16_t x4[4][256];
 	for (int e = 0; e < 256; e++) {
 		uint32_t t = t16[e];
@@ -52,7 +56,9 @@ void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint
 			x4[k][e] = (uint16_t)t;
 		}
 	}
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16x4), x4, sizeof(x4));
+	rc = hipMemcpyToSymbol(HIP_SYMBOL(c_dec_crc16x4), x4, sizeof(x4));
+	if (rc != hipSuccess)
+		return rc;
 	// powers of x modulo x^16 + x^15 + x^2 + 1
 	auto mul = [](uint32_t a, uint32_t b) {
 		uint32_t r = 0;
@@ -80,8 +86,10 @@ void fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint
 			runpow[c][l] = (uint16_t)xpow8(run_bytes * (uint64_t)(63 - l));
 		segpow[c] = (uint16_t)xpow8(run_bytes * 64);
 	}
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_runpow), runpow, sizeof(runpow));
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_dec_segpow), segpow, sizeof(segpow));
+	rc = hipMemcpyToSymbol(HIP_SYMBOL(c_dec_runpow), runpow, sizeof(runpow));
+	if (rc != hipSuccess)
+		return rc;
+	return hipMemcpyToSymbol(HIP_SYMBOL(c_dec_segpow), segpow, sizeof(segpow));
 }
 
 __device__ __forceinline__ int find_stream(const FaStream *streams, uint32_t n, uint64_t p)

@@ -6,7 +6,7 @@
 
 #include "flac_amd_internal.h"
 
-void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
+hipError_t fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st);
 void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,
                      hipStream_t st);

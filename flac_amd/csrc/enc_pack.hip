@@ -18,11 +18,15 @@ __constant__ uint16_t c_crc16x4[4][256];    // table k: CRC-16 of a byte followe
 #define PK_RUN_CLASSES 5
 __constant__ uint16_t c_crc16_runpow[PK_RUN_CLASSES][FA_THREADS];
 
-void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
+hipError_t fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
 {
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_table), t16, 512);
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_pow), pow16, 64);
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc8_table), t8, 256);
+	hipError_t rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_table), t16, 512);
+	if (rc == hipSuccess)
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_pow), pow16, 64);
+	if (rc == hipSuccess)
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc8_table), t8, 256);
+	if (rc != hipSuccess)
+		return rc;
 	static uint16_t x4[4][256];
 	for (int e = 0; e < 256; e++) {
 		uint32_t t = t16[e];
@@ -32,7 +36,9 @@ void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint
 			x4[k][e] = (uint16_t)t;
 		}
 	}
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16x4), x4, sizeof(x4));
+	rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc16x4), x4, sizeof(x4));
+	if (rc != hipSuccess)
+		return rc;
 	// powers of x modulo x^16 + x^15 + x^2 + 1
 	auto mul = [](uint32_t a, uint32_t b) {
 		uint32_t r = 0;
@@ -57,7 +63,7 @@ void fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint
 	for (int c = 0; c < PK_RUN_CLASSES; c++)
 		for (int t = 0; t < FA_THREADS; t++)
 			runpow[c][t] = (uint16_t)xpow8(4ull * (1u << c) * (uint64_t)(FA_THREADS - 1 - t));
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_runpow), runpow, sizeof(runpow));
+	return hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_runpow), runpow, sizeof(runpow));
 }
 
 // product of two polynomials modulo x^16 + x^15 + x^2 + 1

@@ -83,8 +83,9 @@ int flacamd_window(uint32_t apod_type, float apod_param, uint32_t L, float *wind
 typedef struct flacamd_encoder flacamd_encoder;
 
 /* replaces resize_buffers_ (stream_encoder.c:2245): allocates every device buffer for batches of
- * up to max_frames frames on HIP device `device`, uploads the window tables.  No other entry
- * point allocates device memory. */
+ * up to max_frames frames on HIP device `device`, uploads the window tables.  The device-buffer
+ * entry points allocate nothing further; the *_host ones allocate their staging buffers on first
+ * use. */
 int flacamd_encoder_create(const flacamd_encode_params *p, int device, uint32_t max_frames,
                            flacamd_encoder **out);
 void flacamd_encoder_destroy(flacamd_encoder *e);
