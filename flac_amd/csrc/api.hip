@@ -500,6 +500,164 @@ extern "C" int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm
 }
 
 // ---------------------------------------------------------------------------------------------
+// The batch encode for callers that cannot allocate device memory (code under HIP graph capture,
+// serving loops, harnesses that forbid hipMalloc): no handle, every intermediate buffer of the
+// kernels carved out of one static device array per GPU.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char g_static_scratch[FLACAMD_STATIC_SCRATCH_BYTES];
+
+#define STATIC_MAX_DEVICES 64
+#define STATIC_MAX_WINDOW_FLOATS 131072
+#include <mutex>
+namespace {
+struct StaticDevice {
+	unsigned char *ptr;          // this device's copy of g_static_scratch, from hipGetSymbolAddress
+	bool crc_ready;
+	bool win_valid;              // the window tables at the start of the scratch match win_key
+	flacamd_encode_params win_key;
+};
+StaticDevice g_static_dev[STATIC_MAX_DEVICES];
+float g_static_win_host[STATIC_MAX_WINDOW_FLOATS];
+std::mutex g_static_mutex;
+
+struct StaticLayout {
+	size_t windows, stats, autoc, cands, coefs, plans, assign, slots, frame_bytes, offsets, errflag, total;
+};
+
+StaticLayout static_layout(const FaEncParams &P, size_t F)
+{
+	StaticLayout L;
+	size_t o = 0;
+	auto take = [&](size_t bytes) {
+		const size_t at = o;
+		o = (o + bytes + 255) & ~(size_t)255;
+		return at;
+	};
+	const size_t S = P.nsignals;
+	L.windows = take(sizeof(float) * P.napod * P.blocksize);
+	L.stats = take(sizeof(FaSubStat) * F * S);
+	L.autoc = take(sizeof(float) * F * S * P.napod * (FA_MAX_ORDER + 1));
+	L.cands = take(sizeof(FaLpcCand) * F * S * P.ncand);
+	L.coefs = take(sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order);
+	L.plans = take(sizeof(FaPlan) * F * S);
+	L.assign = take(sizeof(uint32_t) * F);
+	L.slots = take((size_t)P.slot_bytes * F + 64);
+	L.frame_bytes = take(sizeof(uint32_t) * F);
+	L.offsets = take(sizeof(uint64_t) * (F + 1));
+	L.errflag = take(16);
+	L.total = o;
+	return L;
+}
+}  // namespace
+
+extern "C" int flacamd_encode_frames_static(const flacamd_encode_params *pin, int device, const void *pcm_dev, uint32_t sample_bytes,
+                                            uint64_t wide_samples, uint32_t first_frame, int is_last, uint32_t *loose_state, void *out_dev,
+                                            size_t out_capacity, uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev, uint32_t *status_dev,
+                                            uint32_t *nframes_out, void *stream)
+{
+	if (!pin)
+		return fa_fail(FLACAMD_E_INVALID, "flacamd_encode_frames_static: null settings");
+	flacamd_encode_params p = *pin;
+	int rc = flacamd_params_resolve(&p);
+	if (rc)
+		return rc;
+	rc = check_partition_reach(p);
+	if (rc)
+		return rc;
+	FaEncParams P;
+	fill_kernel_params(p, P);
+	FaBatch B;
+	uint64_t nf = 0;
+	rc = check_batch(P, pcm_dev, out_dev, sample_bytes, wide_samples, first_frame, is_last, loose_state, B, &nf);
+	if (rc)
+		return rc;
+	if (nframes_out)
+		*nframes_out = (uint32_t)nf;
+	if (nf == 0)
+		return FLACAMD_OK;
+	const size_t win_floats = (size_t)P.napod * P.blocksize;
+	if (P.max_lpc_order > 0 && win_floats > STATIC_MAX_WINDOW_FLOATS)
+		return fa_fail(FLACAMD_E_UNSUPPORTED, "flacamd_encode_frames_static: %zu window samples (apodizations x blocksize) exceed the limit %d", win_floats,
+		               STATIC_MAX_WINDOW_FLOATS);
+	const StaticLayout L = static_layout(P, (size_t)nf);
+	if (L.total > FLACAMD_STATIC_SCRATCH_BYTES)
+		return fa_fail(FLACAMD_E_UNSUPPORTED,
+		               "flacamd_encode_frames_static: a batch of %llu frames with these settings needs %zu bytes of scratch, the static buffer holds %u",
+		               (unsigned long long)nf, L.total, (unsigned)FLACAMD_STATIC_SCRATCH_BYTES);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return fa_fail(FLACAMD_E_DEVICE, "no HIP device available: the FLAC engine needs an AMD GPU");
+	if (device < 0 || device >= ndev || device >= STATIC_MAX_DEVICES)
+		return fa_fail(FLACAMD_E_DEVICE, "HIP device %d out of range (%d present)", device, ndev);
+	HIP_TRY(hipSetDevice(device));
+	hipStream_t st = (hipStream_t)stream;
+
+	std::lock_guard<std::mutex> guard(g_static_mutex);
+	StaticDevice &D = g_static_dev[device];
+	if (!D.ptr) {
+		// each GPU holds its own copy of the array at its own address; the array's name is only a
+		// handle for this lookup, never a pointer host code may pass on
+		void *sym = nullptr;
+		HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(g_static_scratch)));
+		if (!sym)
+			return fa_fail(FLACAMD_E_DEVICE, "hipGetSymbolAddress returned no address for the static scratch buffer");
+		D.ptr = (unsigned char *)sym;
+	}
+	unsigned char *base = D.ptr;
+	if (!D.crc_ready) {
+		uint16_t t16[256], pow16[32];
+		uint8_t t8[256];
+		make_crc_tables(t16, pow16, t8);
+		HIP_TRY(fa_upload_crc_tables(t16, pow16, t8));
+		D.crc_ready = true;
+	}
+	if (P.max_lpc_order > 0) {
+		// the window tables stay in the scratch between calls; they are rebuilt (on the host: the
+		// reference's cosines come from the C library) when blocksize or apodizations change
+		bool same = D.win_valid && D.win_key.blocksize == p.blocksize && D.win_key.num_apodizations == p.num_apodizations;
+		for (uint32_t a = 0; same && a < p.num_apodizations; a++)
+			same = D.win_key.apod_type[a] == p.apod_type[a] && memcmp(&D.win_key.apod_param[a], &p.apod_param[a], sizeof(float)) == 0;
+		if (!same) {
+			D.win_valid = false;
+			for (uint32_t a = 0; a < P.napod; a++) {
+				rc = flacamd_window(p.apod_type[a], p.apod_param[a], P.blocksize, g_static_win_host + (size_t)a * P.blocksize);
+				if (rc)
+					return rc;
+			}
+			// an earlier call on another stream may still be reading the old tables
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipMemcpy(base + L.windows, g_static_win_host, sizeof(float) * win_floats, hipMemcpyHostToDevice));
+			D.win_key = p;
+			D.win_valid = true;
+		}
+	}
+	EncWork W;
+	W.windows = (const float *)(base + L.windows);
+	W.stats = (FaSubStat *)(base + L.stats);
+	W.autoc = (float *)(base + L.autoc);
+	W.cands = (FaLpcCand *)(base + L.cands);
+	W.coefs = (int32_t *)(base + L.coefs);
+	W.plans = (FaPlan *)(base + L.plans);
+	W.assign = (uint32_t *)(base + L.assign);
+	W.slots = (uint32_t *)(base + L.slots);
+	W.errflag = (uint32_t *)(base + L.errflag);
+	// the scratch keeps the last call's contents: the error bits must start at zero (every other
+	// buffer is written before it is read)
+	HIP_TRY(hipMemsetAsync(W.errflag, 0, 16, st));
+	rc = run_batch(P, B, W, pcm_dev, out_dev, out_capacity, frame_bytes_dev ? frame_bytes_dev : (uint32_t *)(base + L.frame_bytes),
+	               frame_offsets_dev ? frame_offsets_dev : (uint64_t *)(base + L.offsets), st, nullptr);
+	if (rc)
+		return rc;
+	if (status_dev)
+		HIP_TRY(hipMemcpyAsync(status_dev, W.errflag, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+	if (loose_state && P.loose_ms) {
+		HIP_TRY(hipMemcpyAsync(loose_state, W.errflag + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
+	return FLACAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // test / debug access to intermediate device results (not part of the public header)
 // ---------------------------------------------------------------------------------------------
 extern "C" int flacamd_debug_read(flacamd_encoder *e, int what, void *dst, size_t bytes)

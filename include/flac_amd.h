@@ -115,6 +115,26 @@ int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm, uint64_t 
                                uint32_t first_frame, int is_last, uint32_t *loose_state,
                                uint8_t *out, size_t out_capacity, uint32_t *frame_bytes,
                                uint32_t *nframes_out, size_t *bytes_out);
+/* No counterpart in the reference.  flacamd_encode_frames for callers that cannot allocate device
+ * memory - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: it
+ * takes the settings instead of a handle and keeps every intermediate buffer of the kernels
+ * (statistics, autocorrelations, candidates, plans, frame slots, window tables) in one static
+ * device array of FLACAMD_STATIC_SCRATCH_BYTES per GPU, which the GPU holds until the process ends.
+ * It calls no hipMalloc / hipFree.  A batch whose buffers do not fit is refused with
+ * FLACAMD_E_UNSUPPORTED (about 1 200 frames of 16-bit stereo at -8), as are more than 131 072
+ * window samples (apodizations x blocksize).  Arguments as for flacamd_encode_frames, plus
+ *   device       HIP device the buffers of this call live on
+ *   status_dev   device word that receives the error bits flacamd_encoder_status would report
+ *                (0 = none, bit 0 a frame outgrew its slot, bit 1 out_dev too small); may be NULL
+ * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams,
+ * two threads) race; calls on different GPUs do not.  The first call on a device, and any call that
+ * changes blocksize or apodizations, uploads tables with a synchronous copy. */
+#define FLACAMD_STATIC_SCRATCH_BYTES (32u << 20)
+int flacamd_encode_frames_static(const flacamd_encode_params *p, int device, const void *pcm_dev,
+                                 uint32_t sample_bytes, uint64_t wide_samples, uint32_t first_frame,
+                                 int is_last, uint32_t *loose_state, void *out_dev, size_t out_capacity,
+                                 uint32_t *frame_bytes_dev, uint64_t *frame_offsets_dev,
+                                 uint32_t *status_dev, uint32_t *nframes_out, void *stream);
 /* After an encode has completed: any device-side error flag (0 = none). */
 int flacamd_encoder_status(flacamd_encoder *e);
 /* Time, in ms, spent in the named stage during the last flacamd_encode_frames call that ran with
