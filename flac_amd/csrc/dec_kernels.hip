@@ -525,6 +525,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		hist[j] = 0;
 	}
 	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
+	uint32_t part_end = 0;         // end of the partition whose parameter was read last
 	uint32_t k = 0, kp1 = 1, raw_bits = 0;
 	bool escape = false;
 	// samples below seg_end are plain Rice symbols with parameter k; fast_end is seg_end while
@@ -582,14 +583,20 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 								for (int j = 0; j < M; j++)
 									q[j] = (uint32_t)j < h.order ? L.q[j][lane] : 0;
 							}
-							k = br_get(r, h.plen);
-							escape = k >= h.pesc;
-							if (escape) {
-								raw_bits = br_get(r, 5);
-								k = 0;
-							}
+							// a first partition as long as the warm-up holds no residual but still has its
+							// parameter in the stream (stream_decoder.c:2734 lets it through, :2747-2767
+							// reads it): its successor's parameter follows at once
+							do {
+								k = br_get(r, h.plen);
+								escape = k >= h.pesc;
+								if (escape) {
+									raw_bits = br_get(r, 5);
+									k = 0;
+								}
+								part_end = h.po > 0 ? part_end + h.psize : bsf;
+							} while (part_end <= i && !r.err && br_pos(r) <= r.bend);
 							kp1 = k + 1;
-							next_part = (h.po > 0) ? ((i / h.psize) + 1) * h.psize : bsf;
+							next_part = part_end;
 							seg_end = escape ? 0 : next_part;
 						}
 						if (!escape) {
@@ -721,6 +728,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		bs_w = t > bs_w ? t : bs_w;
 	}
 	int32_t *frame_tmp = tmp + (size_t)blockIdx.x * P.channels * P.max_blocksize * LW;
+	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
 
 	for (uint32_t c = 0; c < P.channels; c++) {
 		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
@@ -743,15 +751,16 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 				else
 					h.sbps -= h.wasted;
 			}
+			// reserved type codes are "unparseable", a set padding bit is lost sync (stream_decoder.c:2476-2503)
 			if (x & 0x80) r.err = true;
 			else if (x == 0) h.kind = 0;
 			else if (x == 2) h.kind = 1;
-			else if (x < 16) r.err = true;
+			else if (x < 16) r.err = reserved_code = true;
 			else if (x <= 24) {
 				h.kind = 2;
 				h.order = (x >> 1) & 7;
 				if (h.order > 4) r.err = true;
-			} else if (x < 64) r.err = true;
+			} else if (x < 64) r.err = reserved_code = true;
 			else {
 				h.kind = 3;
 				h.order = ((x >> 1) & 31) + 1;
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 				}
 				const uint32_t method = br_get(r, 2);
 				if (method > 1)
-					r.err = true;
+					r.err = reserved_code = true;  // stream_decoder.c:2575,2654
 				if (method == 1) {
 					h.plen = 5;
 					h.pesc = 31;
@@ -838,6 +847,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		cands[j].end_byte = end_byte;
 		// a parse that ran off the end of the input is a cut-off frame, not a malformed one
 		cands[j].status = past ? 4u : r.err ? 2u : 1u;
+		cands[j].reserved = (!past && r.err && reserved_code) ? 1u : 0u;
 	}
 }
 

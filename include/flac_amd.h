@@ -195,7 +195,8 @@ typedef struct {
 	uint32_t assignment; /* FLAC__ChannelAssignment */
 	uint32_t stream;
 	uint32_t status;
-	uint32_t reserved;
+	uint32_t reserved;   /* with status 2: 1 when the parse stopped at a reserved subframe type or
+	                        residual coding method (the reference's UNPARSEABLE_STREAM), else 0 */
 } flacamd_frame_info;
 /* Blocks until the decode finished, then copies up to `capacity` rows.  *truncated is set when
  * the input held more frame headers than the decoder's max_frames or than `capacity`. */
