@@ -5,6 +5,7 @@ oracle/_ref/ (to generate golden vectors, in the build container only) and this 
 drop-in library (to test it the way the reference's own API tests do).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -25,6 +26,11 @@ class FrameHeader(C.Structure):
 
 
 def load(path):
+    if os.path.basename(path).startswith("libflac_amd"):
+        # PyTorch ships its own HIP runtime: in a process that uses both, torch's has to be loaded
+        # first, or whichever initialises second finds no device (flac_amd.lib() does the same)
+        import flac_amd
+        flac_amd.lib()
     lib = C.CDLL(path)
     for kind in ("encoder",) + (("decoder",) if hasattr(lib, "FLAC__stream_decoder_new") else ()):
         getattr(lib, "FLAC__stream_%s_new" % kind).restype = C.c_void_p
