@@ -1319,128 +1319,117 @@ bool next_frame(FLAC__StreamDecoder *d, bool *got_a_frame, bool do_full_decode)
 	}
 }
 
-// seek_to_absolute_sample_ (stream_decoder.c:2973)
-bool seek_to_absolute_sample(FLAC__StreamDecoder *d, FLAC__uint64 stream_length, FLAC__uint64 target_sample)
+// Seeking (what seek_to_absolute_sample_, stream_decoder.c:2973, does for the reference), built on
+// what this decoder has anyway: whatever stretch of the stream is read next is decoded as a window
+// of whole frames whose sample numbers come back in the frame table, and a frame seen while
+// is_seeking is set is inspected by write_audio_frame instead of delivered.  So the hunt is:
+//   1. aim - at the last seek point at or before the target when there is a seek table, else at
+//      (bytes per sample of this stream) x target, a little in front;
+//   2. look - read from there; every frame that ends at or before the target is walked past, the
+//      frame that holds the target ends the hunt (its tail is delivered);
+//   3. correct - if the first frame seen starts beyond the target, aim again further back by the
+//      overshoot (in samples, times the density) plus a margin that doubles each time; if the target
+//      is many frames ahead, aim again further on instead of walking there.
+// The density is measured (stream length / total samples) where STREAMINFO has the totals.
+bool seek_to_absolute_sample(FLAC__StreamDecoder *d, FLAC__uint64 stream_length, FLAC__uint64 target)
 {
 	FLAC__StreamDecoderPrivate *q = d->private_;
 	FLAC__StreamDecoderProtected *p = d->protected_;
-	const FLAC__uint64 first_frame_offset = q->first_frame_offset;
-	FLAC__uint64 lower_bound, upper_bound, lower_bound_sample, upper_bound_sample, this_frame_sample;
-	FLAC__int64 pos = -1;
-	unsigned approx_bytes_per_frame;
-	bool first_seek = true;
-	const FLAC__uint64 total_samples = FLAC__stream_decoder_get_total_samples(d);
 	const FLAC__StreamMetadata_StreamInfo &si = q->stream_info.data.stream_info;
-	const unsigned min_blocksize = si.min_blocksize, max_blocksize = si.max_blocksize;
-	const unsigned max_framesize = si.max_framesize, min_framesize = si.min_framesize;
-	unsigned channels = p->channels, bps = p->bits_per_sample;
-	const FLAC__StreamMetadata_SeekTable *seek_table = q->has_seek_table ? &q->seek_table.data.seek_table : 0;
-	if (channels == 0)
-		channels = si.channels;
-	if (bps == 0)
-		bps = si.bits_per_sample;
-	if (max_framesize > 0)
-		approx_bytes_per_frame = (max_framesize + min_framesize) / 2 + 1;
-	else if (min_blocksize == max_blocksize && min_blocksize > 0)
-		approx_bytes_per_frame = min_blocksize * channels * bps / 8 + 64;
+	const FLAC__uint64 origin = q->first_frame_offset;
+	const FLAC__uint64 total = FLAC__stream_decoder_get_total_samples(d);
+	const unsigned channels = p->channels ? p->channels : si.channels;
+	const unsigned bps = p->bits_per_sample ? p->bits_per_sample : si.bits_per_sample;
+	const unsigned block = si.max_blocksize ? si.max_blocksize : 4096;
+	auto fail = [&]() {
+		p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
+		return false;
+	};
+	if (stream_length <= origin)
+		return fail();
+
+	double density;  // bytes of stream per sample
+	if (total > 0)
+		density = (double)(stream_length - origin) / (double)total;
+	else if (si.max_framesize > 0)
+		density = 0.5 * ((double)si.min_framesize + (double)si.max_framesize) / (double)block;
 	else
-		approx_bytes_per_frame = 4096 * channels * bps / 8 + 64;
+		density = (double)channels * (double)bps / 8.0;
+	const double frame_bytes = density * (double)block + 64.0;
 
-	lower_bound = first_frame_offset;
-	lower_bound_sample = 0;
-	upper_bound = stream_length;
-	upper_bound_sample = total_samples > 0 ? total_samples : target_sample;
-
-	if (seek_table) {
-		FLAC__uint64 new_lower_bound = lower_bound, new_upper_bound = upper_bound;
-		FLAC__uint64 new_lower_bound_sample = lower_bound_sample, new_upper_bound_sample = upper_bound_sample;
-		int i;
-		for (i = (int)seek_table->num_points - 1; i >= 0; i--) {
-			const FLAC__StreamMetadata_SeekPoint &pt = seek_table->points[i];
-			if (pt.sample_number != FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER && pt.frame_samples > 0 &&
-			    (total_samples <= 0 || pt.sample_number < total_samples) && pt.sample_number <= target_sample)
-				break;
+	// 1. aim
+	double aim = (double)origin + density * (double)target - 1.5 * frame_bytes;
+	if (q->has_seek_table) {
+		const FLAC__StreamMetadata_SeekTable &st = q->seek_table.data.seek_table;
+		const FLAC__StreamMetadata_SeekPoint *best = 0;
+		for (unsigned i = 0; i < st.num_points; i++) {
+			const FLAC__StreamMetadata_SeekPoint &pt = st.points[i];
+			if (pt.sample_number == FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER || pt.frame_samples == 0)
+				continue;
+			if (total > 0 && pt.sample_number >= total)
+				continue;
+			if (pt.sample_number <= target && origin + pt.stream_offset < stream_length && (!best || pt.sample_number > best->sample_number))
+				best = &pt;
 		}
-		if (i >= 0) {
-			new_lower_bound = first_frame_offset + seek_table->points[i].stream_offset;
-			new_lower_bound_sample = seek_table->points[i].sample_number;
-		}
-		for (i = 0; i < (int)seek_table->num_points; i++) {
-			const FLAC__StreamMetadata_SeekPoint &pt = seek_table->points[i];
-			if (pt.sample_number != FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER && pt.frame_samples > 0 &&
-			    (total_samples <= 0 || pt.sample_number < total_samples) && pt.sample_number > target_sample)
-				break;
-		}
-		if (i < (int)seek_table->num_points) {
-			new_upper_bound = first_frame_offset + seek_table->points[i].stream_offset;
-			new_upper_bound_sample = seek_table->points[i].sample_number;
-		}
-		if (new_upper_bound >= new_lower_bound) {
-			lower_bound = new_lower_bound;
-			upper_bound = new_upper_bound;
-			lower_bound_sample = new_lower_bound_sample;
-			upper_bound_sample = new_upper_bound_sample;
-		}
+		if (best)
+			aim = (double)(origin + best->stream_offset);  // a frame starts exactly here; a sparse table is made up for by the jump in step 3
 	}
-	if (upper_bound_sample == lower_bound_sample)
-		upper_bound_sample++;
 
-	q->target_sample = target_sample;
-	for (;;) {
-		if (lower_bound_sample >= upper_bound_sample || lower_bound > upper_bound) {
-			p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-			return false;
-		}
-		pos = (FLAC__int64)lower_bound + (FLAC__int64)((double)(target_sample - lower_bound_sample) / (double)(upper_bound_sample - lower_bound_sample) *
-		                                               (double)(upper_bound - lower_bound)) - approx_bytes_per_frame;
-		if (pos >= (FLAC__int64)upper_bound)
-			pos = (FLAC__int64)upper_bound - 1;
-		if (pos < (FLAC__int64)lower_bound)
-			pos = (FLAC__int64)lower_bound;
-		if (q->seek_callback(d, (FLAC__uint64)pos, q->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK) {
-			p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-			return false;
-		}
+	q->target_sample = target;
+	double margin = frame_bytes;
+	FLAC__uint64 pos = 0;
+	for (unsigned attempt = 0; attempt < 64; attempt++) {
+		FLAC__uint64 want = aim <= (double)origin ? origin : (FLAC__uint64)aim;
+		if (want >= stream_length)
+			want = stream_length - 1;
+		pos = want;
+		if (q->seek_callback(d, pos, q->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK)
+			return fail();
 		if (!FLAC__stream_decoder_flush(d))
 			return false;
 		q->unparseable_frame_count = 0;
-		if (!FLAC__stream_decoder_process_single(d)) {
-			p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-			return false;
-		}
-		if (!q->is_seeking)
-			break;
-		this_frame_sample = q->last_frame.header.number.sample_number;
-		if (0 == q->samples_decoded || (this_frame_sample + q->last_frame.header.blocksize >= upper_bound_sample && !first_seek)) {
-			if (pos == (FLAC__int64)lower_bound) {
-				p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-				return false;
+		// 2. look
+		bool first_here = true;
+		for (;;) {
+			q->samples_decoded = 0;
+			if (!FLAC__stream_decoder_process_single(d))
+				return fail();
+			if (!q->is_seeking)
+				return true;  // write_audio_frame found the target in this frame and delivered its tail
+			if (p->state == FLAC__STREAM_DECODER_END_OF_STREAM || q->samples_decoded == 0) {
+				// ran off the end without a frame: look from further back
+				if (pos == origin)
+					return fail();
+				aim = (double)pos - margin;
+				margin *= 2.0;
+				break;
 			}
-			approx_bytes_per_frame = approx_bytes_per_frame ? approx_bytes_per_frame * 2 : 16;
-			continue;
-		}
-		first_seek = false;
-		if (this_frame_sample < lower_bound_sample) {
-			p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-			return false;
-		}
-		if (target_sample < this_frame_sample) {
-			upper_bound_sample = this_frame_sample + q->last_frame.header.blocksize;
-			if (!FLAC__stream_decoder_get_decode_position(d, &upper_bound)) {
-				p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-				return false;
+			const FLAC__uint64 first = q->last_frame.header.number.sample_number;
+			const FLAC__uint64 end = first + q->last_frame.header.blocksize;
+			if (target < first) {
+				// 3. overshoot
+				if (pos == origin || !first_here)
+					return fail();  // the stream's frames do not hold the target
+				aim = (double)pos - (double)(first - target) * density - margin;
+				margin *= 2.0;
+				break;
 			}
-			approx_bytes_per_frame = (unsigned)(2 * (upper_bound - pos) / 3 + 16);
-		} else {
-			lower_bound_sample = this_frame_sample + q->last_frame.header.blocksize;
-			if (!FLAC__stream_decoder_get_decode_position(d, &lower_bound)) {
-				p->state = FLAC__STREAM_DECODER_SEEK_ERROR;
-				return false;
+			first_here = false;
+			// the target lies ahead (end <= target): walk on, or jump when it is far
+			const double ahead = (double)(target - end) * density;
+			if (ahead > 48.0 * frame_bytes) {
+				FLAC__uint64 here;
+				if (!FLAC__stream_decoder_get_decode_position(d, &here))
+					return fail();
+				const double jump = (double)here + ahead - 4.0 * frame_bytes;
+				if (jump > (double)here + 8.0 * frame_bytes) {
+					aim = jump;
+					break;
+				}
 			}
-			approx_bytes_per_frame = (unsigned)(2 * (lower_bound - pos) / 3 + 16);
 		}
 	}
-	return true;
+	return fail();
 }
 
 // ---- FILE* callbacks (stream_decoder.c:3324-3387) ----

@@ -231,3 +231,68 @@ def test_file_api(lib, tmp_path):
         assert lib.FLAC__stream_decoder_init_ogg_file(dec, str(path).encode(), wcb, None, ecb, None) == 1
     finally:
         lib.FLAC__stream_decoder_delete(dec)
+
+
+def _long_stream(lib, seconds=40, seektable=None):
+    from flac_amd.synth import synth_pcm
+    pcm = synth_pcm(seconds=seconds, sample_rate=44100, channels=2, bits_per_sample=16, seed=77)
+    specs = [("seektable", seektable)] if seektable else None
+    meta, frames, ok, _w = L.encode(lib, pcm, 16, 44100, level=5, chunk=1 << 18, seekable=True, total_samples_estimate=pcm.shape[0],
+                                    metadata=specs)
+    assert ok
+    return pcm, meta, frames
+
+
+@pytest.mark.parametrize("variant", ["plain", "seektable", "sparse_seektable", "unknown_total"])
+def test_random_seeks(lib, variant):
+    """What the reference's test_seeking does (src/test_seeking/main.c): many seeks to random samples, with and without a
+    seek table and with a STREAMINFO that does not know the stream's length; every seek must land exactly and decoding
+    must carry on from there."""
+    rng = np.random.default_rng(9)
+    n_est = 40 * 44100
+    table = None
+    if variant == "seektable":
+        table = list(range(0, n_est, 44100 * 2))
+    elif variant == "sparse_seektable":
+        table = [0, n_est // 2 + 12345]
+    pcm, meta, frames = _long_stream(lib, seektable=table)
+    n = pcm.shape[0]
+    if variant == "unknown_total":
+        # STREAMINFO: the 36-bit total sample count (low 4 bits of byte 21 and bytes 22-25 of the block body) set to zero
+        m = bytearray(meta)
+        m[8 + 13] &= 0xf0
+        m[8 + 14:8 + 18] = bytes(4)
+        meta = bytes(m)
+    stream = meta + b"".join(frames)
+    sd = L.StreamDecoder(lib, stream, seekable=True)
+    seeks = [0]
+    plain_seek = sd._seek
+
+    def counting_seek(d, off, c):
+        seeks[0] += 1
+        return plain_seek(d, off, c)
+    try:
+        assert sd.init_status == 0
+        targets = [int(t) for t in rng.integers(0, n, size=60)] + [0, n - 1, n - 4096, 4095, 4096, 4097]
+        for target in targets:
+            sd.blocks.clear()
+            assert sd.call("seek_absolute", C.c_uint64(target)), "seek to %d (%s)" % (target, variant)
+            first, blk = sd.blocks[0]
+            assert first == target
+            assert np.array_equal(blk, pcm[target:target + blk.shape[0]])
+            if target + blk.shape[0] < n:
+                assert sd.call("process_single")
+                nxt, blk2 = sd.blocks[1]
+                assert nxt == target + blk.shape[0] and np.array_equal(blk2, pcm[nxt:nxt + blk2.shape[0]])
+        if variant != "unknown_total":
+            assert not sd.call("seek_absolute", C.c_uint64(n))
+        else:
+            # nobody knows where the stream ends: the hunt runs off the end and reports a seek error, which a flush clears
+            assert not sd.call("seek_absolute", C.c_uint64(n + 5000))
+            assert sd.state() == 6  # FLAC__STREAM_DECODER_SEEK_ERROR
+            assert sd.call("flush")
+            sd.blocks.clear()
+            assert sd.call("seek_absolute", C.c_uint64(1000)) and sd.blocks[0][0] == 1000
+        assert sd.errors == []
+    finally:
+        sd.close()
