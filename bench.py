@@ -298,8 +298,12 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_stream_api:
         try:
+            bench_stream_api(flac_amd, pcm32[:1 << 20], do_md5=False)  # first use of the stream layer's buffers and threads
             result["end_to_end"] = bench_stream_api(flac_amd, pcm32)
             result["end_to_end"]["without_md5"] = bench_stream_api(flac_amd, pcm32, do_md5=False)
+            result["end_to_end"]["without_md5_null_sink"] = bench_stream_api(flac_amd, pcm32, do_md5=False, sink="null")
+            result["end_to_end"]["four_encoders_four_threads"] = bench_stream_api(flac_amd, pcm32, do_md5=True, threads=4)
+            result["end_to_end"]["four_encoders_four_threads_without_md5"] = bench_stream_api(flac_amd, pcm32, do_md5=False, threads=4)
         except Exception as exc:
             result["end_to_end"] = {"error": str(exc)}
 
@@ -324,46 +328,82 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_stream_api(flac_amd, pcm32, do_md5=True):
-    """The same stream through the libFLAC-compatible API from host memory: int32 samples in,
-    MD5, PCIe both ways, write callbacks.  Never the headline value.  do_md5=False switches the
-    digest off (FLAC__stream_encoder_set_do_md5, stream_encoder.c:1414), which shows what the
-    copies and the GPU work take on their own."""
+def bench_stream_api(flac_amd, pcm32, do_md5=True, threads=1, sink="tmpfs"):
+    """The same stream through the libFLAC-compatible API from host memory: int32 samples in through
+    FLAC__stream_encoder_process_interleaved in 1 Mi-sample calls, MD5, PCIe both ways, the library's
+    own FILE write / seek / tell callbacks (FLAC__stream_encoder_init_file, what the `flac` tool uses)
+    onto a tmpfs file.  Never the headline value.  do_md5=False switches the digest off
+    (FLAC__stream_encoder_set_do_md5, stream_encoder.c:1414), which shows what the copies and the GPU
+    work take on their own.  threads > 1: that many encoder objects on as many host threads, each
+    coding its own copy of the stream on the one GPU (aggregate rate)."""
     import ctypes as C
+    import tempfile
+    import threading
     lib = flac_amd.lib()
     wide, ch = pcm32.shape
     data = np.ascontiguousarray(pcm32, dtype=np.int32)
-    WRITE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_ubyte), C.c_size_t, C.c_uint, C.c_uint, C.c_void_p)
-    got = [0]
-
-    def on_write(_e, _buf, nbytes, _samples, _frame, _c):
-        got[0] += nbytes
-        return 0
-    cb = WRITE_CB(on_write)
     lib.FLAC__stream_encoder_new.restype = C.c_void_p
-    enc = C.c_void_p(lib.FLAC__stream_encoder_new())
-    for name, v in (("channels", ch), ("bits_per_sample", BPS), ("sample_rate", RATE), ("compression_level", LEVEL)):
-        getattr(lib, "FLAC__stream_encoder_set_" + name)(enc, C.c_uint(v))
-    lib.FLAC__stream_encoder_set_total_samples_estimate(enc, C.c_uint64(wide))
-    if not do_md5:
-        lib.FLAC__stream_encoder_set_do_md5(enc, C.c_int(0))
-    t0 = time.perf_counter()
-    st = lib.FLAC__stream_encoder_init_stream(enc, cb, None, None, None, None)
-    if st != 0:
-        raise RuntimeError("init_stream status %d" % st)
-    t1 = time.perf_counter()
-    chunk = 1 << 20
-    for pos in range(0, wide, chunk):
-        n = min(chunk, wide - pos)
-        if not lib.FLAC__stream_encoder_process_interleaved(enc, data[pos:pos + n].ctypes.data_as(C.c_void_p), C.c_uint(n)):
-            raise RuntimeError("process_interleaved failed")
-    if not lib.FLAC__stream_encoder_finish(enc):
-        raise RuntimeError("finish failed")
-    t2 = time.perf_counter()
-    lib.FLAC__stream_encoder_delete(enc)
-    return {"value": wide * ch / (t2 - t1) / 1e6, "unit": "MSamples/s", "seconds": t2 - t1, "init_seconds": t1 - t0, "bytes": got[0],
-            "what": "FLAC__stream_encoder_process_interleaved of the same 600 s stream from host int32: %shost<->device copies and "
-                    "write callbacks included; one host thread" % ("MD5, " if do_md5 else "no MD5, ")}
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    results = [None] * threads
+    encs = []
+    for t in range(threads):
+        enc = C.c_void_p(lib.FLAC__stream_encoder_new())
+        for name, v in (("channels", ch), ("bits_per_sample", BPS), ("sample_rate", RATE), ("compression_level", LEVEL)):
+            getattr(lib, "FLAC__stream_encoder_set_" + name)(enc, C.c_uint(v))
+        lib.FLAC__stream_encoder_set_total_samples_estimate(enc, C.c_uint64(wide))
+        if not do_md5:
+            lib.FLAC__stream_encoder_set_do_md5(enc, C.c_int(0))
+        encs.append(enc)
+
+    def run(t):
+        enc = encs[t]
+        path = "/dev/null" if sink == "null" else os.path.join(tmpdir, "flac_amd_bench_%d_%d.flac" % (os.getpid(), t))
+        t0 = time.perf_counter()
+        st = lib.FLAC__stream_encoder_init_file(enc, path.encode(), None, None)
+        if st != 0:
+            results[t] = RuntimeError("init_file status %d" % st)
+            return
+        t1 = time.perf_counter()
+        chunk = 1 << 20
+        ok = True
+        for pos in range(0, wide, chunk):
+            n = min(chunk, wide - pos)
+            if not lib.FLAC__stream_encoder_process_interleaved(enc, data[pos:pos + n].ctypes.data_as(C.c_void_p), C.c_uint(n)):
+                ok = False
+                break
+        ok = bool(lib.FLAC__stream_encoder_finish(enc)) and ok
+        t2 = time.perf_counter()
+        size = os.path.getsize(path) if os.path.exists(path) else 0
+        if sink != "null":
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        results[t] = (t1 - t0, t2 - t1, size) if ok else RuntimeError("encode failed")
+
+    t_start = time.perf_counter()
+    if threads == 1:
+        run(0)
+    else:
+        ths = [threading.Thread(target=run, args=(t,)) for t in range(threads)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    t_all = time.perf_counter() - t_start
+    for enc in encs:
+        lib.FLAC__stream_encoder_delete(enc)
+    for r in results:
+        if isinstance(r, Exception):
+            raise r
+    init_s = max(r[0] for r in results)
+    proc_s = max(r[1] for r in results)
+    out = {"value": threads * wide * ch / (t_all - init_s if threads > 1 else proc_s) / 1e6, "unit": "MSamples/s", "seconds": proc_s, "init_seconds": init_s,
+           "file_bytes": results[0][2], "threads": threads,
+           "what": "FLAC__stream_encoder_init_file + process_interleaved + finish of the same 600 s stream from host int32: %shost<->device "
+                   "copies and the library's FILE callbacks onto %s included; %d host thread(s) calling, %d encoder object(s) on one GPU"
+                   % ("MD5, " if do_md5 else "no MD5, ", "/dev/null" if sink == "null" else "a tmpfs file", threads, threads)}
+    return out
 
 
 def bench_decode(torch, flac_amd, dev, local_rank, world, dist, flac_dev, flac_bytes, wide, bs, nframes, args, pcm_dev, stream_wide):

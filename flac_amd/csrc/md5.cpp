@@ -159,6 +159,28 @@ void fa_md5_accumulate_interleaved(FaMd5 *c, const int32_t *samples, size_t coun
 		fa_md5_update(c, buf, fill);
 }
 
+void fa_md5_accumulate_container(FaMd5 *c, const void *samples, unsigned container_bytes, size_t count, unsigned bps_bytes)
+{
+	if (container_bytes == 4) {
+		fa_md5_accumulate_interleaved(c, (const int32_t *)samples, count, bps_bytes);
+		return;
+	}
+	const int16_t *s16 = (const int16_t *)samples;
+	if (bps_bytes == 2) {
+		// little-endian 16-bit samples are the digest's input as they stand
+		fa_md5_update(c, (const uint8_t *)s16, count * 2);
+		return;
+	}
+	uint8_t buf[4096];
+	for (size_t i = 0; i < count;) {
+		size_t n = count - i < sizeof buf ? count - i : sizeof buf;
+		for (size_t k = 0; k < n; k++)
+			buf[k] = (uint8_t)s16[i + k];
+		fa_md5_update(c, buf, n);
+		i += n;
+	}
+}
+
 int fa_md5_default_mode(void)
 {
 	const char *e = getenv("FLAC_AMD_MD5");

@@ -3,17 +3,26 @@
 // Mirrors src/libFLAC/stream_encoder.c: settings and their validation, the stream prologue, the
 // one-sample look-ahead blocking of process / process_interleaved, per-frame write / tell / seek
 // callback sequencing, seek-table fill-in and the finish()-time STREAMINFO rewrite.  Frames
-// themselves come from flacamd_encode_frames_host in batches; callbacks run on the caller's thread.
+// themselves come from flacamd_encode_frames in batches that are pipelined: while the caller's
+// samples are being staged for batch k+1, batch k is on the GPU and batch k-1's frames are coming
+// back; the MD5 of the samples runs on a thread of its own.  Callbacks run on the caller's thread.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
+#include <emmintrin.h>
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include "flac_amd.h"
 #include "md5.h"
-
-#include <thread>
 #include "stream_common.h"
 
 extern "C" {
@@ -84,16 +93,60 @@ struct FLAC__StreamEncoderPrivate {
 	flacamd_decoder *verify_dec;
 	unsigned batch_frames;
 	unsigned configured_blocksize;
-	std::vector<int32_t> *ring;    // interleaved samples not yet encoded
-	size_t buffered;               // wide samples in ring
-	std::vector<uint8_t> *out;
-	std::vector<uint32_t> *frame_bytes;
+	struct EncPipe *pipe;          // staging slots, streams, helper threads
 	uint32_t loose_state;
 	// verify error report (stream_encoder.h:1242)
 	FLAC__uint64 ve_absolute_sample;
 	unsigned ve_frame, ve_channel, ve_sample;
 	FLAC__int32 ve_expected, ve_got;
 	FLAC__bool is_being_deleted;
+};
+
+#define ENC_SLOTS 3
+
+struct EncSlot {
+	uint8_t *pin_in, *dev_in;
+	uint8_t *pin_out, *dev_out;
+	uint32_t *pin_fb, *dev_fb;
+	uint64_t *pin_total, *dev_offs;
+	hipEvent_t uploaded, computed, done;
+	size_t fill;        // wide samples staged so far
+	size_t wide;        // wide samples of the submitted batch
+	uint32_t nframes;
+	uint32_t first_frame;
+	uint64_t md5_ticket;
+	bool in_flight;
+};
+
+struct EncPipe {
+	int device;
+	unsigned cw;              // container width of the staging buffers, bytes per sample
+	unsigned channels, blocksize, bytes_per_sample;
+	size_t slot_samples;      // wide samples a slot can stage: (batch_frames + 1) blocks
+	size_t in_bytes, out_cap, out_guess;
+	EncSlot slot[ENC_SLOTS];
+	unsigned filling;         // slot the caller's samples go to
+	unsigned oldest;          // oldest slot in flight (frames go out in submission order)
+	unsigned in_flight;
+	hipStream_t s_in, s_comp, s_out;
+	// MD5 of the staged samples, in order, on its own thread (FLAC__MD5Accumulate, stream_encoder.c:2870,
+	// is serial work over the whole stream: here it overlaps everything else)
+	std::thread md5_thread;
+	std::mutex mu;
+	std::condition_variable cv;
+	struct Md5Job { const uint8_t *p; size_t samples; };
+	std::deque<Md5Job> md5_jobs;
+	uint64_t md5_posted, md5_finished;
+	bool md5_quit, md5_on;
+	bool loose_carry;         // batches do not start on loose mid/side decision boundaries
+	FaMd5 *md5;
+	// helpers that share out the staging of large process() calls
+	std::vector<std::thread> copiers;
+	struct CopyJob { const int32_t *src; uint8_t *dst; size_t n; };
+	std::vector<CopyJob> copy_jobs;
+	uint64_t copy_generation;
+	unsigned copy_pending;
+	bool copy_quit;
 };
 
 namespace {
@@ -144,6 +197,8 @@ void set_defaults(FLAC__StreamEncoder *e)
 	q->client_data = 0;
 }
 
+void pipe_destroy(FLAC__StreamEncoderPrivate *q);
+
 void free_run_state(FLAC__StreamEncoder *e)
 {
 	FLAC__StreamEncoderPrivate *q = e->private_;
@@ -160,12 +215,7 @@ void free_run_state(FLAC__StreamEncoder *e)
 		flacamd_decoder_destroy(q->verify_dec);
 		q->verify_dec = 0;
 	}
-	q->ring->clear();
-	q->ring->shrink_to_fit();
-	q->buffered = 0;
-	q->out->clear();
-	q->out->shrink_to_fit();
-	q->frame_bytes->clear();
+	pipe_destroy(q);
 }
 
 #define UNINIT_OR_FALSE(e) \
@@ -227,75 +277,306 @@ bool write_metadata_buffer(FLAC__StreamEncoder *e, const std::vector<uint8_t> &b
 	return true;
 }
 
-// Encode `wide` samples from the front of the ring (whole blocks, or the final short block) and
-// hand the frames to the client in order: process_frame_ (stream_encoder.c:2861) + write_bitbuffer_.
-bool encode_and_emit(FLAC__StreamEncoder *e, size_t wide, bool is_last)
+// ---------------------------------------------------------------------------------------------
+// The batch pipeline.  A slot is one batch on its way through: pinned host staging for the samples
+// (at container width: int16 for streams of up to 16 bits, which halves what crosses PCIe and puts
+// stereo on the kernels' one-word-per-wide-sample paths, else int32), the same on the device, the
+// device and pinned host buffers for the frames.  Three slots rotate: one being filled by the
+// caller, one on the GPU, one whose frames are coming back.  Three HIP streams keep the roles
+// apart - uploads, kernels (which share the encoder handle's work buffers and therefore run in
+// order), downloads - chained by events.  The download copies the frame sizes, the total, and a
+// guessed share of the frame bytes at once; what a batch produced beyond the guess is fetched when
+// the batch is collected.
+// ---------------------------------------------------------------------------------------------
+// int32 samples to the staging width.  Values keep their low 16 bits, as a cast does; streams of up
+// to 16 bits hold nothing above them.
+void narrow_samples(const int32_t *src, uint8_t *dst, size_t n, unsigned cw)
+{
+	if (cw == 4) {
+		memcpy(dst, src, n * 4);
+		return;
+	}
+	int16_t *d = (int16_t *)dst;
+	size_t i = 0;
+	for (; i + 8 <= n; i += 8) {
+		__m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 4));
+		a = _mm_srai_epi32(_mm_slli_epi32(a, 16), 16);
+		b = _mm_srai_epi32(_mm_slli_epi32(b, 16), 16);
+		_mm_storeu_si128((__m128i *)(d + i), _mm_packs_epi32(a, b));
+	}
+	for (; i < n; i++)
+		d[i] = (int16_t)src[i];
+}
+
+void md5_worker(EncPipe *P)
+{
+	for (;;) {
+		EncPipe::Md5Job job;
+		{
+			std::unique_lock<std::mutex> lk(P->mu);
+			P->cv.wait(lk, [&] { return P->md5_quit || !P->md5_jobs.empty(); });
+			if (P->md5_jobs.empty())
+				return;
+			job = P->md5_jobs.front();
+			P->md5_jobs.pop_front();
+		}
+		fa_md5_accumulate_container(P->md5, job.p, P->cw, job.samples, P->bytes_per_sample);
+		{
+			std::lock_guard<std::mutex> lk(P->mu);
+			P->md5_finished++;
+		}
+		P->cv.notify_all();
+	}
+}
+
+void copy_worker(EncPipe *P, unsigned me)
+{
+	uint64_t seen = 0;
+	for (;;) {
+		EncPipe::CopyJob job;
+		{
+			std::unique_lock<std::mutex> lk(P->mu);
+			P->cv.wait(lk, [&] { return P->copy_quit || P->copy_generation != seen; });
+			if (P->copy_quit)
+				return;
+			seen = P->copy_generation;
+			job = P->copy_jobs[me];
+		}
+		if (job.n)
+			narrow_samples(job.src, job.dst, job.n, P->cw);
+		{
+			std::lock_guard<std::mutex> lk(P->mu);
+			P->copy_pending--;
+		}
+		P->cv.notify_all();
+	}
+}
+
+// Stage n interleaved samples (n counts single samples, not wide ones); large runs are shared out.
+void stage_run(EncPipe *P, const int32_t *src, uint8_t *dst, size_t n)
+{
+	const size_t big = (size_t)1 << 19;
+	if (n < big) {
+		narrow_samples(src, dst, n, P->cw);
+		return;
+	}
+	if (P->copiers.empty()) {
+		unsigned want = 3;
+		if (const char *env = getenv("FLAC_AMD_COPY_THREADS"))
+			want = (unsigned)atoi(env);
+		if (want > 15)
+			want = 15;
+		P->copy_jobs.resize(want);
+		for (unsigned i = 0; i < want; i++)
+			P->copiers.emplace_back(copy_worker, P, i);
+		if (P->copiers.empty()) {
+			narrow_samples(src, dst, n, P->cw);
+			return;
+		}
+	}
+	const size_t parts = P->copiers.size() + 1;
+	const size_t per = ((n / parts) + 63) & ~(size_t)63;
+	size_t at = 0;
+	{
+		std::lock_guard<std::mutex> lk(P->mu);
+		for (size_t i = 0; i < P->copiers.size(); i++) {
+			const size_t m = at + per <= n ? per : n - at;
+			P->copy_jobs[i] = {src + at, dst + at * P->cw, m};
+			at += m;
+		}
+		P->copy_pending = (unsigned)P->copiers.size();
+		P->copy_generation++;
+	}
+	P->cv.notify_all();
+	narrow_samples(src + at, dst + at * P->cw, n - at, P->cw);
+	std::unique_lock<std::mutex> lk(P->mu);
+	P->cv.wait(lk, [&] { return P->copy_pending == 0; });
+}
+
+void pipe_destroy(FLAC__StreamEncoderPrivate *q)
+{
+	EncPipe *P = q->pipe;
+	if (!P)
+		return;
+	{
+		std::lock_guard<std::mutex> lk(P->mu);
+		P->md5_quit = true;
+		P->copy_quit = true;
+	}
+	P->cv.notify_all();
+	if (P->md5_thread.joinable())
+		P->md5_thread.join();
+	for (auto &t : P->copiers)
+		t.join();
+	(void)hipSetDevice(P->device);
+	if (P->s_in) {
+		(void)hipStreamSynchronize(P->s_in);
+		(void)hipStreamSynchronize(P->s_comp);
+		(void)hipStreamSynchronize(P->s_out);
+	}
+	for (EncSlot &S : P->slot) {
+		(void)hipHostFree(S.pin_in);
+		(void)hipHostFree(S.pin_out);
+		(void)hipHostFree(S.pin_fb);
+		(void)hipFree(S.dev_in);
+		(void)hipFree(S.dev_out);
+		(void)hipFree(S.dev_fb);
+		(void)hipFree(S.dev_offs);
+		if (S.uploaded) (void)hipEventDestroy(S.uploaded);
+		if (S.computed) (void)hipEventDestroy(S.computed);
+		if (S.done) (void)hipEventDestroy(S.done);
+	}
+	if (P->s_in) (void)hipStreamDestroy(P->s_in);
+	if (P->s_comp) (void)hipStreamDestroy(P->s_comp);
+	if (P->s_out) (void)hipStreamDestroy(P->s_out);
+	delete P;
+	q->pipe = 0;
+}
+
+bool pipe_create(FLAC__StreamEncoder *e)
 {
 	FLAC__StreamEncoderProtected *p = e->protected_;
 	FLAC__StreamEncoderPrivate *q = e->private_;
+	EncPipe *P = new (std::nothrow) EncPipe();
+	if (!P)
+		return false;
+	q->pipe = P;
+	P->device = fa_stream_device();
+	P->cw = p->bits_per_sample <= 16 ? 2 : 4;
+	P->channels = p->channels;
+	P->blocksize = p->blocksize;
+	P->bytes_per_sample = (p->bits_per_sample + 7) / 8;
+	P->slot_samples = ((size_t)q->batch_frames + 1) * p->blocksize;
+	P->in_bytes = P->slot_samples * p->channels * P->cw;
+	P->out_cap = flacamd_encoder_max_output_bytes(q->dev, q->batch_frames + 1);
+	// lossless audio rarely needs more than 3/4 of its PCM size; a batch that does is topped up at collection
+	P->out_guess = (size_t)((double)P->slot_samples * p->channels * P->bytes_per_sample * 0.75) + 4096;
+	if (P->out_guess > P->out_cap)
+		P->out_guess = P->out_cap;
+	P->filling = P->oldest = P->in_flight = 0;
+	P->s_in = P->s_comp = P->s_out = 0;
+	P->md5_posted = P->md5_finished = 0;
+	P->md5_quit = false;
+	P->md5_on = p->do_md5 != 0;
+	P->md5 = &q->md5;
+	{
+		unsigned period = (unsigned)((double)p->sample_rate * 0.4 / (double)p->blocksize + 0.5);  // stream_encoder.c:871
+		if (period == 0)
+			period = 1;
+		P->loose_carry = p->loose_mid_side_stereo && (q->batch_frames % period) != 0;
+	}
+	P->copy_generation = 0;
+	P->copy_pending = 0;
+	P->copy_quit = false;
+	memset(P->slot, 0, sizeof P->slot);
+	if (hipSetDevice(P->device) != hipSuccess)
+		return false;
+	bool ok = hipStreamCreateWithFlags(&P->s_in, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&P->s_comp, hipStreamNonBlocking) == hipSuccess &&
+	          hipStreamCreateWithFlags(&P->s_out, hipStreamNonBlocking) == hipSuccess;
+	const size_t nfmax = (size_t)q->batch_frames + 1;
+	for (EncSlot &S : P->slot) {
+		ok = ok && hipHostMalloc((void **)&S.pin_in, P->in_bytes + 64, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipHostMalloc((void **)&S.pin_out, P->out_cap + 64, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipHostMalloc((void **)&S.pin_fb, sizeof(uint32_t) * nfmax + 16, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipMalloc((void **)&S.dev_in, P->in_bytes + 64) == hipSuccess;
+		ok = ok && hipMalloc((void **)&S.dev_out, P->out_cap + 64) == hipSuccess;
+		ok = ok && hipMalloc((void **)&S.dev_fb, sizeof(uint32_t) * nfmax + 16) == hipSuccess;
+		ok = ok && hipMalloc((void **)&S.dev_offs, sizeof(uint64_t) * (nfmax + 1)) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&S.uploaded, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&S.computed, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&S.done, hipEventDisableTiming) == hipSuccess;
+		if (!ok)
+			break;
+		S.pin_total = (uint64_t *)(S.pin_fb + ((nfmax + 1) & ~(size_t)1));
+	}
+	if (!ok)
+		return false;
+	if (P->md5_on)
+		P->md5_thread = std::thread(md5_worker, P);
+	return true;
+}
+
+// Hand the frames of the oldest batch in flight to the client: process_frame_'s tail
+// (stream_encoder.c:2885-2915) + write_bitbuffer_ (:2379), in frame order.
+bool collect_oldest(FLAC__StreamEncoder *e)
+{
+	FLAC__StreamEncoderProtected *p = e->protected_;
+	FLAC__StreamEncoderPrivate *q = e->private_;
+	EncPipe *P = q->pipe;
+	EncSlot &S = P->slot[P->oldest];
 	const unsigned bs = q->configured_blocksize, ch = p->channels;
-	const int32_t *pcm = q->ring->data();
-	const uint32_t nfr_max = (uint32_t)((wide + bs - 1) / bs);
-	q->out->resize(flacamd_encoder_max_output_bytes(q->dev, nfr_max));
-	q->frame_bytes->resize(nfr_max);
-	uint32_t nf = 0;
-	size_t total = 0;
-	// The MD5 of these samples (FLAC__MD5Accumulate, process_frame_ stream_encoder.c:2870) is serial
-	// host work; it runs on a helper thread while the GPU codes the same samples.  Every sample
-	// passes here exactly once and in order, so the digest is the one the reference computes.
-	std::thread md5_helper;
-	if (p->do_md5)
-		md5_helper = std::thread([q, pcm, wide, ch, p]() {
-			fa_md5_accumulate_interleaved(&q->md5, pcm, wide * ch, (p->bits_per_sample + 7) / 8);
-		});
-	int rc = flacamd_encode_frames_host(q->dev, pcm, wide, q->current_frame_number, is_last ? 1 : 0, &q->loose_state, q->out->data(),
-	                                    q->out->size(), q->frame_bytes->data(), &nf, &total);
-	if (md5_helper.joinable())
-		md5_helper.join();
-	if (rc != FLACAMD_OK) {
-		p->state = rc == FLACAMD_E_NOMEM ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+	auto retire = [&]() {
+		S.in_flight = false;
+		P->oldest = (P->oldest + 1) % ENC_SLOTS;
+		P->in_flight--;
+	};
+	if (hipSetDevice(P->device) != hipSuccess || hipEventSynchronize(S.done) != hipSuccess || flacamd_encoder_status(q->dev) != FLACAMD_OK) {
+		p->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		retire();
 		return false;
 	}
+	const size_t total = (size_t)*S.pin_total;
+	if (total > P->out_cap) {
+		p->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		retire();
+		return false;
+	}
+	if (total > P->out_guess && hipMemcpy(S.pin_out + P->out_guess, S.dev_out + P->out_guess, total - P->out_guess, hipMemcpyDeviceToHost) != hipSuccess) {
+		p->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		retire();
+		return false;
+	}
+	const size_t wide = S.wide;
+	const uint32_t nf = S.nframes;
 	if (p->verify) {
-		// verify_write_callback_ (stream_encoder.c:4161): decode what was just produced, compare
-		std::vector<int32_t> back(wide * ch);
+		// verify_write_callback_ (stream_encoder.c:4161): decode what was just produced, compare with what went in
+		// (both at the staging width, which holds every sample exactly)
+		std::vector<uint8_t> back(wide * ch * P->cw);
 		flacamd_stream_desc sd;
 		sd.byte_offset = 0;
 		sd.byte_length = total;
 		sd.sample_offset = 0;
 		sd.total_samples = wide;
-		sd.first_sample = (FLAC__uint64)q->current_frame_number * bs;
+		sd.first_sample = (FLAC__uint64)S.first_frame * bs;
 		uint32_t dfr = 0, bad = 0;
 		uint64_t dwide = 0;
-		rc = flacamd_decode_streams_host(q->verify_dec, q->out->data(), total, &sd, 1, back.data(), 4, wide, &dfr, &dwide, &bad);
+		const int rc = flacamd_decode_streams_host(q->verify_dec, S.pin_out, total, &sd, 1, back.data(), P->cw, wide, &dfr, &dwide, &bad);
 		if (rc != FLACAMD_OK || bad || dfr != nf) {
 			p->state = FLAC__STREAM_ENCODER_VERIFY_DECODER_ERROR;
+			retire();
 			return false;
 		}
-		if (memcmp(back.data(), pcm, sizeof(int32_t) * wide * ch) != 0) {
-			for (size_t i = 0; i < wide * ch; i++)
-				if (back[i] != pcm[i]) {
+		if (memcmp(back.data(), S.pin_in, back.size()) != 0) {
+			for (size_t i = 0; i < wide * ch; i++) {
+				const int32_t want = P->cw == 2 ? ((const int16_t *)S.pin_in)[i] : ((const int32_t *)S.pin_in)[i];
+				const int32_t got = P->cw == 2 ? ((const int16_t *)back.data())[i] : ((const int32_t *)back.data())[i];
+				if (want != got) {
 					const size_t w = i / ch;
-					q->ve_absolute_sample = (FLAC__uint64)q->current_frame_number * bs + w;
-					q->ve_frame = q->current_frame_number + (unsigned)(w / bs);
+					q->ve_absolute_sample = (FLAC__uint64)S.first_frame * bs + w;
+					q->ve_frame = S.first_frame + (unsigned)(w / bs);
 					q->ve_channel = (unsigned)(i % ch);
 					q->ve_sample = (unsigned)(w % bs);
-					q->ve_expected = pcm[i];
-					q->ve_got = back[i];
+					q->ve_expected = want;
+					q->ve_got = got;
 					break;
 				}
+			}
 			p->state = FLAC__STREAM_ENCODER_VERIFY_MISMATCH_IN_AUDIO_DATA;
+			retire();
 			return false;
 		}
 	}
 	size_t off = 0, done = 0;
+	bool ok = true;
 	for (uint32_t f = 0; f < nf; f++) {
 		const unsigned n = (unsigned)((wide - done) < bs ? (wide - done) : bs);
-		const size_t fb = (*q->frame_bytes)[f];
+		const size_t fb = S.pin_fb[f];
 		p->blocksize = n;  // finish() sets the short block's size before its frame is written (:1319)
-		if (write_frame(e, q->out->data() + off, fb, n) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
-			p->state = FLAC__STREAM_ENCODER_CLIENT_ERROR;
-			return false;
+		if (off + fb > total || write_frame(e, S.pin_out + off, fb, n) != FLAC__STREAM_ENCODER_WRITE_STATUS_OK) {
+			p->state = off + fb > total ? FLAC__STREAM_ENCODER_FRAMING_ERROR : FLAC__STREAM_ENCODER_CLIENT_ERROR;
+			ok = false;
+			break;
 		}
 		// write_bitbuffer_ :2418-2421, process_frame_ :2913-2915
 		FLAC__StreamMetadata_StreamInfo &si = q->streaminfo.data.stream_info;
@@ -307,32 +588,98 @@ bool encode_and_emit(FLAC__StreamEncoder *e, size_t wide, bool is_last)
 		done += n;
 	}
 	p->blocksize = bs;
-	// drop the consumed samples
-	const size_t keep = q->buffered - wide;
-	if (keep)
-		memmove(q->ring->data(), q->ring->data() + wide * ch, sizeof(int32_t) * keep * ch);
-	q->buffered = keep;
+	retire();
+	return ok;
+}
+
+// Send the first `wide` staged samples of the filling slot on their way (whole blocks, or with
+// is_last the stream's final blocks) and move the samples staged beyond them to the next slot.
+bool submit_filling(FLAC__StreamEncoder *e, size_t wide, bool is_last)
+{
+	FLAC__StreamEncoderProtected *p = e->protected_;
+	FLAC__StreamEncoderPrivate *q = e->private_;
+	EncPipe *P = q->pipe;
+	EncSlot &S = P->slot[P->filling];
+	const unsigned ch = p->channels;
+	const size_t wbytes = (size_t)ch * P->cw;
+	auto device_failed = [&]() {
+		p->state = FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		return false;
+	};
+	if (hipSetDevice(P->device) != hipSuccess)
+		return device_failed();
+	S.wide = wide;
+	S.first_frame = q->current_frame_number + [&] {
+		// frames of the batches in flight have not reached current_frame_number yet
+		uint32_t ahead = 0;
+		for (unsigned k = 0, i = P->oldest; k < P->in_flight; k++, i = (i + 1) % ENC_SLOTS)
+			ahead += P->slot[i].nframes;
+		return ahead;
+	}();
+	if (hipMemcpyAsync(S.dev_in, S.pin_in, wide * wbytes, hipMemcpyHostToDevice, P->s_in) != hipSuccess || hipEventRecord(S.uploaded, P->s_in) != hipSuccess ||
+	    hipStreamWaitEvent(P->s_comp, S.uploaded, 0) != hipSuccess)
+		return device_failed();
+	// The loose mid/side decision of a batch's last leader frame has to reach the next batch (through the host, which
+	// makes the call wait for the kernels) unless every batch starts on a decision boundary
+	// (stream_encoder.c:2952-2962), which the batch size is chosen for.
+	uint32_t nf = 0;
+	const int rc = flacamd_encode_frames(q->dev, S.dev_in, P->cw, wide, S.first_frame, is_last ? 1 : 0, P->loose_carry ? &q->loose_state : 0, S.dev_out,
+	                                     P->out_cap, S.dev_fb, S.dev_offs, &nf, P->s_comp);
+	if (rc != FLACAMD_OK) {
+		p->state = rc == FLACAMD_E_NOMEM ? FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR : FLAC__STREAM_ENCODER_FRAMING_ERROR;
+		return false;
+	}
+	S.nframes = nf;
+	if (hipEventRecord(S.computed, P->s_comp) != hipSuccess || hipStreamWaitEvent(P->s_out, S.computed, 0) != hipSuccess ||
+	    hipMemcpyAsync(S.pin_fb, S.dev_fb, sizeof(uint32_t) * nf, hipMemcpyDeviceToHost, P->s_out) != hipSuccess ||
+	    hipMemcpyAsync(S.pin_total, S.dev_offs + nf, sizeof(uint64_t), hipMemcpyDeviceToHost, P->s_out) != hipSuccess ||
+	    hipMemcpyAsync(S.pin_out, S.dev_out, P->out_guess, hipMemcpyDeviceToHost, P->s_out) != hipSuccess || hipEventRecord(S.done, P->s_out) != hipSuccess)
+		return device_failed();
+	if (P->md5_on) {
+		{
+			std::lock_guard<std::mutex> lk(P->mu);
+			P->md5_jobs.push_back({S.pin_in, wide * ch});
+			S.md5_ticket = ++P->md5_posted;
+		}
+		P->cv.notify_all();
+	}
+	S.in_flight = true;
+	P->in_flight++;
+	// the next slot to fill: free it first if it is still on its way
+	const unsigned next = (P->filling + 1) % ENC_SLOTS;
+	if (P->in_flight == ENC_SLOTS) {
+		if (!collect_oldest(e))
+			return false;
+	}
+	EncSlot &N = P->slot[next];
+	if (P->md5_on && N.md5_ticket) {
+		std::unique_lock<std::mutex> lk(P->mu);
+		P->cv.wait(lk, [&] { return P->md5_finished >= N.md5_ticket; });
+	}
+	const size_t left = S.fill - wide;
+	if (left)
+		memcpy(N.pin_in, S.pin_in + wide * wbytes, left * wbytes);
+	N.fill = left;
+	S.fill = 0;
+	P->filling = next;
+	// frames that are ready go out now rather than when their slot is needed
+	while (P->in_flight && hipEventQuery(P->slot[P->oldest].done) == hipSuccess)
+		if (!collect_oldest(e))
+			return false;
 	return true;
 }
 
 // The reference encodes a block once blocksize+1 samples are buffered (OVERREAD_, :504-515), so
-// the last block is always left for finish().  Batched: encode every whole block that is followed
-// by at least one more sample, once a full batch of them has accumulated (or when forced).
-bool drain_ring(FLAC__StreamEncoder *e, bool force)
+// the last block is always left for finish().  Batched: a batch goes out when batch_frames whole
+// blocks are staged and at least one more sample follows them.
+bool submit_if_full(FLAC__StreamEncoder *e)
 {
 	FLAC__StreamEncoderPrivate *q = e->private_;
-	const unsigned bs = q->configured_blocksize;
-	for (;;) {
-		if (q->buffered <= bs)
-			return true;
-		size_t ready = (q->buffered - 1) / bs;
-		if (ready > q->batch_frames)
-			ready = q->batch_frames;
-		if (ready < q->batch_frames && !force)
-			return true;
-		if (!encode_and_emit(e, ready * bs, false))
-			return false;
-	}
+	EncPipe *P = q->pipe;
+	const size_t batch = (size_t)q->batch_frames * q->configured_blocksize;
+	if (P->slot[P->filling].fill > batch)
+		return submit_filling(e, batch, false);
+	return true;
 }
 
 
@@ -548,7 +895,6 @@ FLAC__StreamEncoderInitStatus init_stream_internal(FLAC__StreamEncoder *e, FLAC_
 	q->first_seekpoint_to_check = 0;
 	q->samples_written = 0;
 	q->loose_state = 0;
-	q->buffered = 0;
 	q->configured_blocksize = p->blocksize;
 	p->streaminfo_offset = p->seektable_offset = p->audio_offset = 0;
 	q->ve_absolute_sample = 0;
@@ -560,8 +906,22 @@ FLAC__StreamEncoderInitStatus init_stream_internal(FLAC__StreamEncoder *e, FLAC_
 		const char *env = getenv("FLAC_AMD_BATCH_FRAMES");
 		size_t bf = env ? (size_t)strtoul(env, 0, 10) : 0;
 		if (bf == 0) {
-			bf = ((size_t)32 << 20) / ((size_t)p->blocksize * p->channels);  // about 32 M samples in flight
-			if (bf > 2048) bf = 2048;
+			// about 2 M samples per batch, three batches in flight (measured: larger batches leave the caller's thread
+			// waiting at the pipeline's ends, smaller ones pay per-batch launches); a stream known to be short gets
+			// buffers to match (two batches of half its length)
+			bf = ((size_t)2 << 20) / ((size_t)p->blocksize * p->channels);
+			if (bf > 1024) bf = 1024;
+			if (p->total_samples_estimate > 0) {
+				const size_t half = (size_t)((p->total_samples_estimate / p->blocksize + 2) / 2 + 1);
+				if (half < bf) bf = half;
+			}
+			if (bf < 8) bf = 8;
+			if (p->loose_mid_side_stereo) {
+				// batches that start where the loose mid/side decision is taken afresh need no state from their predecessor
+				size_t period = (size_t)((double)p->sample_rate * 0.4 / (double)p->blocksize + 0.5);
+				if (period == 0) period = 1;
+				bf = (bf + period - 1) / period * period;
+			}
 		}
 		if (bf < 1) bf = 1;
 		q->batch_frames = (unsigned)bf;
@@ -579,7 +939,10 @@ FLAC__StreamEncoderInitStatus init_stream_internal(FLAC__StreamEncoder *e, FLAC_
 			return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 		}
 	}
-	q->ring->reserve(((size_t)q->batch_frames + 2) * p->blocksize * p->channels);
+	if (!pipe_create(e)) {
+		p->state = FLAC__STREAM_ENCODER_MEMORY_ALLOCATION_ERROR;
+		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
+	}
 
 	// stream prologue (:1029-1116): "fLaC", STREAMINFO, VORBIS_COMMENT if the client gave none, client blocks
 	std::vector<uint8_t> buf;
@@ -662,6 +1025,10 @@ FLAC__StreamEncoderInitStatus init_file_internal(FLAC__StreamEncoder *e, const c
 		e->protected_->state = FLAC__STREAM_ENCODER_IO_ERROR;
 		return FLAC__STREAM_ENCODER_INIT_STATUS_ENCODER_ERROR;
 	}
+	// frames arrive a batch at a time: a large stdio buffer turns thousands of small writes into a few
+	// (only for a file this library opened itself; the buffer is the C library's own)
+	if (filename)
+		(void)setvbuf(f, 0, _IOFBF, (size_t)1 << 20);
 	return init_FILE_internal(e, f, progress, client_data, is_ogg);
 }
 
@@ -683,9 +1050,6 @@ FLAC__StreamEncoder *FLAC__stream_encoder_new(void)
 		free(e);
 		return 0;
 	}
-	e->private_->ring = new (std::nothrow) std::vector<int32_t>();
-	e->private_->out = new (std::nothrow) std::vector<uint8_t>();
-	e->private_->frame_bytes = new (std::nothrow) std::vector<uint32_t>();
 	set_defaults(e);
 	e->protected_->state = FLAC__STREAM_ENCODER_UNINITIALIZED;
 	return e;
@@ -697,9 +1061,6 @@ void FLAC__stream_encoder_delete(FLAC__StreamEncoder *e)
 		return;
 	e->private_->is_being_deleted = 1;
 	(void)FLAC__stream_encoder_finish(e);
-	delete e->private_->ring;
-	delete e->private_->out;
-	delete e->private_->frame_bytes;
 	free(e->private_);
 	free(e->protected_);
 	free(e);
@@ -742,17 +1103,24 @@ FLAC__bool FLAC__stream_encoder_finish(FLAC__StreamEncoder *e)
 	bool error = false;
 	if (p->state == FLAC__STREAM_ENCODER_UNINITIALIZED)
 		return 1;
-	if (p->state == FLAC__STREAM_ENCODER_OK && !q->is_being_deleted) {
-		if (!drain_ring(e, true))
+	if (p->state == FLAC__STREAM_ENCODER_OK && !q->is_being_deleted && q->pipe) {
+		// what is staged goes out as the stream's last blocks, the final one short or not (:1317-1322)
+		EncPipe *P = q->pipe;
+		if (P->slot[P->filling].fill != 0 && !submit_filling(e, P->slot[P->filling].fill, true))
 			error = true;
-		else if (q->buffered != 0) {
-			// the last block, short or not (:1317-1322)
-			if (!encode_and_emit(e, q->buffered, true))
+		while (!error && P->in_flight)
+			if (!collect_oldest(e))
 				error = true;
-		}
 	}
-	if (p->do_md5 && q->dev)
+	if (p->do_md5 && q->dev && q->pipe) {
+		// every sample has been posted by now; wait for the digest thread to have taken them all in
+		EncPipe *P = q->pipe;
+		{
+			std::unique_lock<std::mutex> lk(P->mu);
+			P->cv.wait(lk, [&] { return P->md5_finished >= P->md5_posted; });
+		}
 		fa_md5_final(&q->md5, q->streaminfo.data.stream_info.md5sum);
+	}
 	if (!q->is_being_deleted) {
 		if (p->state == FLAC__STREAM_ENCODER_OK) {
 			if (q->seek_callback) {
@@ -783,17 +1151,19 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 	FLAC__StreamEncoderPrivate *q = e->private_;
 	if (p->state != FLAC__STREAM_ENCODER_OK)
 		return 0;
+	EncPipe *P = q->pipe;
 	const unsigned ch = p->channels;
+	const size_t wbytes = (size_t)ch * P->cw;
 	unsigned done = 0;
 	while (done < samples) {
-		// keep the ring bounded: top up to one batch plus the look-ahead, then drain
-		const size_t room = (size_t)(q->batch_frames + 1) * q->configured_blocksize + 1 - q->buffered;
+		// the samples are copied (narrowed) straight into the filling slot's pinned staging buffer
+		EncSlot &S = P->slot[P->filling];
+		const size_t room = P->slot_samples - S.fill;
 		const unsigned n = (unsigned)((samples - done) < room ? (samples - done) : room);
-		q->ring->resize((q->buffered + n) * ch);
-		memcpy(q->ring->data() + q->buffered * ch, buffer + (size_t)done * ch, sizeof(int32_t) * (size_t)n * ch);
-		q->buffered += n;
+		stage_run(P, buffer + (size_t)done * ch, S.pin_in + S.fill * wbytes, (size_t)n * ch);
+		S.fill += n;
 		done += n;
-		if (!drain_ring(e, false))
+		if (!submit_if_full(e))
 			return 0;
 	}
 	return 1;
@@ -802,20 +1172,35 @@ FLAC__bool FLAC__stream_encoder_process_interleaved(FLAC__StreamEncoder *e, cons
 FLAC__bool FLAC__stream_encoder_process(FLAC__StreamEncoder *e, const FLAC__int32 *const buffer[], unsigned samples)
 {
 	FLAC__StreamEncoderProtected *p = e->protected_;
+	FLAC__StreamEncoderPrivate *q = e->private_;
 	if (p->state != FLAC__STREAM_ENCODER_OK)
 		return 0;
+	EncPipe *P = q->pipe;
 	const unsigned ch = p->channels;
-	std::vector<int32_t> tmp;
-	const unsigned step = 65536;
-	for (unsigned done = 0; done < samples;) {
-		const unsigned n = samples - done < step ? samples - done : step;
-		tmp.resize((size_t)n * ch);
-		for (unsigned c = 0; c < ch; c++)
-			for (unsigned i = 0; i < n; i++)
-				tmp[(size_t)i * ch + c] = buffer[c][done + i];
-		if (!FLAC__stream_encoder_process_interleaved(e, tmp.data(), n))
-			return 0;
+	const size_t wbytes = (size_t)ch * P->cw;
+	unsigned done = 0;
+	while (done < samples) {
+		EncSlot &S = P->slot[P->filling];
+		const size_t room = P->slot_samples - S.fill;
+		const unsigned n = (unsigned)((samples - done) < room ? (samples - done) : room);
+		uint8_t *dst = S.pin_in + S.fill * wbytes;
+		// planar in, interleaved (and narrowed) into the staging buffer
+		for (unsigned c = 0; c < ch; c++) {
+			const FLAC__int32 *src = buffer[c] + done;
+			if (P->cw == 2) {
+				int16_t *d = (int16_t *)dst + c;
+				for (unsigned i = 0; i < n; i++)
+					d[(size_t)i * ch] = (int16_t)src[i];
+			} else {
+				int32_t *d = (int32_t *)dst + c;
+				for (unsigned i = 0; i < n; i++)
+					d[(size_t)i * ch] = src[i];
+			}
+		}
+		S.fill += n;
 		done += n;
+		if (!submit_if_full(e))
+			return 0;
 	}
 	return 1;
 }
