@@ -100,7 +100,8 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 		} \
 	} while (0)
 	ALLOC(d->streams, sizeof(FaStream) * d->max_streams);
-	ALLOC(d->block_counts, sizeof(uint32_t) * nb);
+	// per 4 KiB of input: a count of frame headers, and behind the counts four 64-bit lane masks
+	ALLOC(d->block_counts, sizeof(uint32_t) * ((size_t)nb + 2) + sizeof(uint64_t) * 4 * (size_t)nb);
 	ALLOC(d->block_offsets, sizeof(uint64_t) * (nb + 1));
 	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
 	ALLOC(d->ncand, 16);

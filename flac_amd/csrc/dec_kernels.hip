@@ -214,15 +214,16 @@ __device__ bool parse_frame_header(const uint8_t *d, uint64_t p, const FaDecPara
 #define SYNC_BYTES_PER_THREAD 16
 #define SYNC_THREADS 256
 
-template <bool EMIT>
-__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts,
-                                                           const uint64_t *block_offsets, FaFrameCand *cands, uint32_t *ncand_out)
+// The counting pass: every byte position is tested for a frame header; what comes out is the number of
+// headers per 4 KiB block and, per wave, the mask of lanes (16-byte runs) that hold one.
+__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts)
 {
 	__shared__ uint32_t wsum[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint64_t p0 = ((uint64_t)blockIdx.x * SYNC_THREADS + tid) * SYNC_BYTES_PER_THREAD;
-	FaFrameCand found[2];  // more than two real headers in 16 bytes cannot happen
-	uint32_t n = 0;
+	uint32_t n = 0;  // headers in this run (more than two real ones in 16 bytes cannot happen)
+	// the lane masks lie behind the counts, four 64-bit words per block
+	uint64_t *masks = (uint64_t *)(block_counts + ((gridDim.x + 1) & ~1u)) + (size_t)blockIdx.x * (SYNC_THREADS / 64);
 	// the thread's 16 bytes and the one after them, as five words; only positions that hold the
 	// two sync bytes are looked at further
 	uint32_t w[SYNC_BYTES_PER_THREAD / 4 + 1];
@@ -236,12 +237,19 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 		}
 	}
 	uint32_t hits = 0;
+	// most 16-byte runs hold no 0xff byte at all: one test per word (a byte of w is 0xff where the byte of ~w is zero)
+	uint32_t any_ff = 0;
 #pragma unroll
-	for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
-		const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff;
-		const uint32_t b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
-		if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
-			hits |= 1u << i;
+	for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4; k++)
+		any_ff |= (~w[k] - 0x01010101u) & w[k] & 0x80808080u;
+	if (any_ff) {
+#pragma unroll
+		for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
+			const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff;
+			const uint32_t b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
+			if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
+				hits |= 1u << i;
+		}
 	}
 	while (hits) {
 		const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
@@ -250,11 +258,8 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 		if (p >= P.flac_bytes)
 			break;
 		FaFrameCand c;
-		if (parse_frame_header(d, p, P, streams, c)) {
-			if (n < 2)
-				found[n] = c;
+		if (parse_frame_header(d, p, P, streams, c))
 			n++;
-		}
 	}
 	if (n > 2)
 		n = 2;
@@ -271,23 +276,14 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 	uint32_t off = 0;
 	for (uint32_t w = 0; w < wv; w++)
 		off += wsum[w];
-	if (!EMIT) {
-		if (tid == SYNC_THREADS - 1)
-			block_counts[blockIdx.x] = off + inc;
-	} else {
-		const uint64_t base = block_offsets[blockIdx.x] + off + inc - n;
-		for (uint32_t i = 0; i < n; i++)
-			if (base + i < P.max_frames)
-				cands[base + i] = found[i];
-		if (blockIdx.x == gridDim.x - 1 && tid == SYNC_THREADS - 1) {
-			const uint64_t total = block_offsets[blockIdx.x] + off + inc;
-			ncand_out[0] = total > P.max_frames ? P.max_frames : (uint32_t)total;
-			ncand_out[1] = total > P.max_frames ? 1u : 0u;  // overflow flag
-		}
-	}
+	const uint64_t m = __ballot(n > 0);
+	if (lane == 0)
+		masks[wv] = m;
+	if (tid == SYNC_THREADS - 1)
+		block_counts[blockIdx.x] = off + inc;
 }
 
-// exclusive scan of the per-block counts (single block)
+// exclusive scan of the per-block counts (single block, eight counts per thread and round)
 __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint32_t n, uint64_t *offsets)
 {
 	__shared__ uint64_t wsum[16];
@@ -296,10 +292,16 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 	if (tid == 0)
 		carry = 0;
 	__syncthreads();
-	for (uint32_t base = 0; base < n; base += 1024) {
-		const uint32_t i = base + tid;
-		const uint64_t v = i < n ? counts[i] : 0;
-		uint64_t inc = v;
+	for (uint32_t base = 0; base < n; base += 8 * 1024) {
+		const uint32_t i0 = base + tid * 8;
+		uint32_t v[8];
+		uint64_t mine = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			v[k] = i0 + k < n ? counts[i0 + k] : 0u;
+			mine += v[k];
+		}
+		uint64_t inc = mine;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint64_t t = __shfl_up(inc, o, 64);
@@ -312,12 +314,77 @@ __global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint3
 		uint64_t off = carry;
 		for (uint32_t w = 0; w < wv; w++)
 			off += wsum[w];
-		if (i < n)
-			offsets[i] = off + inc - v;
+		uint64_t run = off + inc - mine;
+#pragma unroll
+		for (uint32_t k = 0; k < 8; k++) {
+			if (i0 + k < n)
+				offsets[i0 + k] = run;
+			run += v[k];
+		}
 		__syncthreads();
 		if (tid == 1023)
 			carry = off + inc;
 		__syncthreads();
+	}
+}
+
+// The emitting pass: one thread per 4 KiB block of the counting pass.  It walks the block's lane
+// masks in byte order and parses the (few) flagged 16-byte runs again, which puts the headers into
+// the table in the order of their positions.
+__global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint8_t *d, const FaStream *streams, const uint32_t *block_counts,
+                                                      const uint64_t *block_offsets, FaFrameCand *cands, uint32_t *ncand_out, uint32_t nb)
+{
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	if (b >= nb)
+		return;
+	const uint32_t count = block_counts[b];
+	uint64_t at = block_offsets[b];
+	if (b == nb - 1) {
+		const uint64_t total = at + count;
+		ncand_out[0] = total > P.max_frames ? P.max_frames : (uint32_t)total;
+		ncand_out[1] = total > P.max_frames ? 1u : 0u;  // overflow flag
+	}
+	if (count == 0)
+		return;
+	const uint64_t *masks = (const uint64_t *)(block_counts + ((nb + 1) & ~1u)) + (size_t)b * (SYNC_THREADS / 64);
+	for (uint32_t wv = 0; wv < SYNC_THREADS / 64; wv++) {
+		uint64_t m = masks[wv];
+		while (m) {
+			const uint32_t lane = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+			m &= m - 1;
+			const uint64_t p0 = ((uint64_t)b * SYNC_THREADS + wv * 64 + lane) * SYNC_BYTES_PER_THREAD;
+			// the run and the byte after it in one go, as the counting pass reads them
+			const uint64_t nwords = (P.flac_bytes + 3) / 4;
+			uint32_t w[SYNC_BYTES_PER_THREAD / 4 + 1];
+#pragma unroll
+			for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4 + 1; k++) {
+				const uint64_t idx = p0 / 4 + k;
+				w[k] = idx < nwords ? ((const uint32_t *)d)[idx] : 0u;
+			}
+			uint32_t hits = 0;
+#pragma unroll
+			for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
+				const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff;
+				const uint32_t b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
+				if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
+					hits |= 1u << i;
+			}
+			uint32_t n = 0;
+			while (hits && n < 2) {
+				const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
+				hits &= hits - 1;
+				const uint64_t p = p0 + i;
+				if (p >= P.flac_bytes)
+					break;
+				FaFrameCand c;
+				if (parse_frame_header(d, p, P, streams, c)) {
+					if (at < P.max_frames)
+						cands[at] = c;
+					at++;
+					n++;
+				}
+			}
+		}
 	}
 }
 
@@ -987,6 +1054,43 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 	__syncthreads();
 	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * LW;
 	const uint32_t row = tile_samples * ch;  // elements per frame in the tile
+	if (ch == 2 && LW >= 4) {
+		// stereo, the common case: four frames' values of one sample are 16 bytes of each plane, and a
+		// frame's left/right pair goes to LDS as one word (int16 output) or two
+		const int32_t *pa = frame_tmp, *pb = frame_tmp + (size_t)P.max_blocksize * LW;
+		for (uint32_t idx = tid * 4; idx < tile_samples * LW; idx += 256 * 4) {
+			const uint32_t fl0 = idx & (LW - 1), ii = idx >> lw_log;
+			const uint32_t i = i0 + ii;
+			if (i >= P.max_blocksize)
+				continue;
+			const int4 a4 = *(const int4 *)(pa + (size_t)i * LW + fl0);
+			const int4 b4 = *(const int4 *)(pb + (size_t)i * LW + fl0);
+			const int32_t av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t fl = fl0 + j;
+				if (!(sc[fl].status == 1 && i < sc[fl].blocksize))
+					continue;
+				const uint32_t assignment = sc[fl].assignment;
+				int32_t a = av[j], b = bv[j];
+				// stream_decoder.c:2067-2102
+				if (assignment == 1)
+					b = a - b;
+				else if (assignment == 2)
+					a = a + b;
+				else if (assignment == 3) {
+					int32_t mid = (int32_t)((uint32_t)a << 1);
+					mid |= (b & 1);
+					a = (mid + b) >> 1;
+					b = (mid - b) >> 1;
+				}
+				if (sb == 2)
+					((uint32_t *)lds)[(fl * row + ii * 2) >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+				else
+					((int2 *)lds)[(fl * row + ii * 2) >> 1] = make_int2(a, b);
+			}
+		}
+	} else
 	for (uint32_t idx = tid; idx < tile_samples * LW; idx += 256) {
 		const uint32_t fl = idx & (LW - 1), ii = idx >> lw_log;
 		const uint32_t i = i0 + ii;
@@ -1044,7 +1148,17 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 			continue;
 		const uint64_t obase = (st.sample_offset + rel) * ch;
 		const uint32_t nel = nvalid * ch;
-		for (uint32_t e = lane; e < nel; e += 64) {
+		// 16 bytes per lane where the run starts on a 16-byte boundary on both sides, single samples for the rest
+		uint8_t *gdst = (uint8_t *)out + obase * sb;
+		const uint8_t *lsrc = lds + (size_t)fl * row * sb;
+		uint32_t e0 = 0;
+		if ((((uintptr_t)gdst | (uintptr_t)((size_t)fl * row * sb)) & 15) == 0) {
+			const uint32_t nvec = (nel * sb) >> 4;
+			for (uint32_t v = lane; v < nvec; v += 64)
+				((uint4 *)gdst)[v] = ((const uint4 *)lsrc)[v];
+			e0 = (nvec << 4) / sb;
+		}
+		for (uint32_t e = e0 + lane; e < nel; e += 64) {
 			if (sb == 2)
 				((int16_t *)out)[obase + e] = ((const int16_t *)lds)[fl * row + e];
 			else
@@ -1097,9 +1211,9 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
                         FaFrameCand *cands, uint32_t *ncand, hipStream_t st)
 {
 	const uint32_t nb = fa_dec_sync_blocks(P.flac_bytes);
-	hipLaunchKernelGGL(k_dec_sync<false>, dim3(nb), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts, block_offsets, cands, ncand);
+	hipLaunchKernelGGL(k_dec_sync, dim3(nb), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts);
 	hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets);
-	hipLaunchKernelGGL(k_dec_sync<true>, dim3(nb), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts, block_offsets, cands, ncand);
+	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, block_offsets, cands, ncand, nb);
 }
 
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
