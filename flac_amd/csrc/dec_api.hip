@@ -27,6 +27,9 @@ struct flacamd_decoder {
 	FaFrameCand *cands;
 	uint32_t *ncand;                // [0] count, [1] overflow flag
 	int32_t *tmp;
+	int32_t *vals;                  // cooperative form: values per (frame, channel) as read from the stream
+	FaSubDesc *subs;                // cooperative form: what the restore pass needs per (frame, channel)
+	uint32_t coop, coop_lw;         // the cooperative form is used, and its frames per group
 	unsigned long long *result;     // good frames, wide samples, bad candidates
 	int profiling, have_times;
 	hipEvent_t ev[FLACAMD_DEC_STAGES + 1];
@@ -48,6 +51,8 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipFree(d->cands);
 	(void)hipFree(d->ncand);
 	(void)hipFree(d->tmp);
+	(void)hipFree(d->vals);
+	(void)hipFree(d->subs);
 	(void)hipFree(d->result);
 	(void)hipFree(d->stage_in);
 	(void)hipFree(d->stage_out);
@@ -119,6 +124,21 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 		d->lw = lw;
 	}
 	ALLOC(d->result, 32);
+	// The cooperative form (dec_coop.hip: a wave per frame, then a lane per subframe) is an opt-in variant,
+	// FLAC_AMD_DEC_MODE=coop.  Measured against the lane-per-frame form it is 20-30 % faster on batches of up to
+	// ~4000 stereo frames and on eight-channel input, slower beyond (10 min of 16-bit stereo: 2.06 vs 1.79 ms), so
+	// the lane form stays the default.
+	{
+		d->coop = 0;
+		if (const char *env = getenv("FLAC_AMD_DEC_MODE"))
+			if (!strcmp(env, "coop"))
+				d->coop = 1;
+		d->coop_lw = fa_dec_coop_lw(channels);
+		if (d->coop) {
+			ALLOC(d->vals, sizeof(int32_t) * ((size_t)max_frames * channels * max_blocksize + 64));
+			ALLOC(d->subs, sizeof(FaSubDesc) * (size_t)max_frames * channels);
+		}
+	}
 #undef ALLOC
 	uint16_t t16[256], pow16[32];
 	uint8_t t8[256];
@@ -210,7 +230,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.nstreams = nstreams;
 	P.max_frames = d->max_frames;
 	P.number_scale = d->number_scale;
-	P.lw = d->lw;
+	P.lw = d->coop ? d->coop_lw : d->lw;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	const bool prof = d->profiling != 0;
@@ -225,7 +245,10 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, (size_t)out_capacity_wide * d->channels * out_sample_bytes, st));
 	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->block_offsets, d->cands, d->ncand, st);
 	STAGE_MARK();
-	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, st);
+	if (d->coop)
+		fa_dec_launch_coop(P, flac_dev, d->streams, d->cands, d->ncand, d->vals, d->subs, d->tmp, st);
+	else
+		fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, st);
 	STAGE_MARK();
 	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, st);
 	STAGE_MARK();
