@@ -597,7 +597,7 @@ __global__ __launch_bounds__(LPC_LANES) void k_lpc(FaEncParams P, FaBatch B, con
 	FaLpcCand *my_cands = cands + (size_t)sub * P.ncand;
 	int32_t *my_coefs = coefs + (size_t)sub * P.ncand * P.max_lpc_order;
 	FaLpcCand none;
-	none.valid = 0; none.order = 0; none.precision = 0; none.shift = 0; none.rice = 0; none.wide = 0; none.pad[0] = none.pad[1] = 0;
+	none.valid = 0; none.order = 0; none.precision = 0; none.shift = 0; none.rice = 0; none.wide = 0; none.sumq32 = 0;
 	for (uint32_t c = 0; c < P.ncand; c++)
 		my_cands[c] = none;
 	if (bsf < 4 || st.is_constant || P.max_lpc_order == 0)
@@ -697,6 +697,7 @@ __global__ __launch_bounds__(LPC_LANES) void k_lpc(FaEncParams P, FaBatch B, con
 				else if (shift < -16)
 					continue;
 				double qerr = 0.0;
+				uint32_t sumq = 0;
 				int32_t *q = my_coefs + (size_t)slot * P.max_lpc_order;
 				for (uint32_t j = 0; j <= i; j++) {
 					const float c = (float)(-lpc[j * LPC_LANES + lane]);
@@ -709,6 +710,7 @@ __global__ __launch_bounds__(LPC_LANES) void k_lpc(FaEncParams P, FaBatch B, con
 					else if (v < qmin) v = qmin;
 					qerr -= v;
 					q[j] = v;
+					sumq += abs32(v);
 				}
 				FaLpcCand cd;
 				cd.valid = 1;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(LPC_LANES) void k_lpc(FaEncParams P, FaBatch B, con
 				cd.shift = (int8_t)(shift < 0 ? 0 : shift);
 				cd.rice = (uint8_t)rice;
 				cd.wide = (sbps + precision + ilog2u(order) <= 32) ? 0 : 1;  // stream_encoder.c:3592
-				cd.pad[0] = cd.pad[1] = 0;
+				cd.sumq32 = (uint16_t)((sumq + 31) >> 5);  // at most 32 * 2^14 / 32
 				my_cands[slot] = cd;
 			}
 		}

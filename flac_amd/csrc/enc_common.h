@@ -460,11 +460,13 @@ __device__ __forceinline__ bool fa_split_exact(uint64_t sumq, uint32_t sbps)
 }
 
 // The 64-bit prediction (lpc.c:531) spelled out tap by tap, for the candidates the two-taps paths
-// cannot do exactly.  getd(k) returns sample (16 t - HIST + k) of the window; qp as above.  Four
-// samples at a time, so that it adds little to the register budget of the kernel around it: it is
-// there for correctness (coefficient sets that large do not come out of a real signal), not speed.
-template <int HIST, int MAXORDER, typename GetD, typename Q>
-__device__ __forceinline__ void lpc_pred16_exact64(GetD getd, const Q &qp, uint32_t order, int shift, int32_t (&pred)[FA_CHUNK])
+// cannot do exactly.  getd(k) returns sample (16 t - HIST + k) of the window, getq(j) coefficient j
+// (the same in every lane).  wrap: the candidate's sum is the reference's wrapping 32-bit one
+// (lpc.c:265), i.e. the 64-bit sum truncated before the shift.  Four samples at a time, so that it
+// adds little to the register budget of the kernel around it: it is there for correctness
+// (coefficient sets that large do not come out of a real signal), not speed.
+template <int HIST, int MAXORDER, typename GetD, typename GetQ>
+__device__ __forceinline__ void lpc_pred16_exact64(GetD getd, GetQ getq, uint32_t order, int shift, bool wrap, int32_t (&pred)[FA_CHUNK])
 {
 #pragma unroll
 	for (int blk = 0; blk < FA_CHUNK / 4; blk++) {
@@ -472,8 +474,7 @@ __device__ __forceinline__ void lpc_pred16_exact64(GetD getd, const Q &qp, uint3
 #pragma unroll
 		for (int j = 0; j < MAXORDER; j++) {
 			if ((uint32_t)j < order) {
-				const int32_t qw = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[j >> 1]);
-				const int64_t qj = (j & 1) ? (int64_t)(int16_t)(qw & 0xffff) : (int64_t)(qw >> 16);
+				const int64_t qj = (int64_t)getq(j);
 #pragma unroll
 				for (int i = 0; i < 4; i++)
 					sum[i] += qj * (int64_t)getd(HIST + blk * 4 + i - 1 - j);
@@ -481,7 +482,123 @@ __device__ __forceinline__ void lpc_pred16_exact64(GetD getd, const Q &qp, uint3
 		}
 #pragma unroll
 		for (int i = 0; i < 4; i++)
-			pred[blk * 4 + i] = (int32_t)(sum[i] >> shift);
+			pred[blk * 4 + i] = wrap ? ((int32_t)sum[i] >> shift) : (int32_t)(sum[i] >> shift);
+	}
+}
+
+// The same as x[i] = 2^31 - residual, the form lpc_negres16_* produce at shift 0.
+template <int HIST, int MAXORDER, typename GetD, typename GetQ>
+__device__ __forceinline__ void lpc_negres16_exact64(GetD getd, GetQ getq, uint32_t order, int shift, bool wrap, uint32_t (&x)[FA_CHUNK])
+{
+#pragma unroll
+	for (int blk = 0; blk < FA_CHUNK / 4; blk++) {
+		int64_t sum[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int j = 0; j < MAXORDER; j++) {
+			if ((uint32_t)j < order) {
+				const int64_t qj = (int64_t)getq(j);
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					sum[i] += qj * (int64_t)getd(HIST + blk * 4 + i - 1 - j);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int32_t pred = wrap ? ((int32_t)sum[i] >> shift) : (int32_t)(sum[i] >> shift);
+			x[blk * 4 + i] = 0x80000000u - ((uint32_t)getd(HIST + blk * 4 + i) - (uint32_t)pred);
+		}
+	}
+}
+
+// coefficient j out of words that hold two 16-bit coefficients each, the even one in the high half
+// (the packing lpc_pred16_dot2 and lpc_pred16_split take)
+template <typename Q>
+__device__ __forceinline__ int32_t packed_coef(const Q &qp, int j)
+{
+	const int32_t qw = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qp[j >> 1]);
+	return (j & 1) ? (int32_t)(int16_t)(qw & 0xffff) : (qw >> 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The residual out of the multiply-add chain itself.  With c = 2^31 as the chain's starting value,
+// the sample as one more tap with coefficient -2^shift and a LOGICAL shift at the end,
+//     x = (2^31 + sum q[j] d[i-1-j] - d[i] 2^shift) >> shift
+//       = 2^(31-shift) + floor(sum / 2^shift) - d[i]  =  B - residual,    B = 2^(31-shift),
+// as long as |sum - d 2^shift| < 2^31 as an integer, which the caller guarantees per candidate from
+// the sum of the coefficients' magnitudes (fa_fold_exact).  |residual| = |x - B| is then one
+// v_sad_u32 against the scalar B: two instructions per sample besides the taps, where prediction,
+// shift, subtraction and absolute value were four.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fa_fold_exact(uint64_t sumq, uint32_t shift, uint32_t sbps)
+{
+	return shift <= 15 && ((sumq + (1ull << shift)) << (sbps - 1)) < (1ull << 31);
+}
+
+// acc + |a - b|, unsigned: written the way the compiler turns into v_sad_u32
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc) { return acc + (a > b ? a - b : b - a); }
+
+// Samples and coefficients fit 16 bits: two taps per v_dot2_i32_i16.  PW[k] holds samples
+// (16 t - HIST + k - 1) and (.. + k) of the tile in its low and high half (PW[0]: zero and the first);
+// with c[0] = -2^shift and c[m] = q[m-1], qf[jj] holds c[2 jj + 1] in its low half and c[2 jj] in its
+// high half (0 past the order): order / 2 + 1 instructions per sample.  c31: 2^31 in a vector register.
+template <int HIST, int MAXORDER, typename Q>
+__device__ __forceinline__ void lpc_negres16_dot2(const int32_t (&PW)[HIST + FA_CHUNK], const Q &qf, uint32_t order, uint32_t shift, uint32_t c31,
+                                                  uint32_t (&x)[FA_CHUNK])
+{
+	int32_t sum[FA_CHUNK];
+	{
+		const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qf[0]);
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(sum[i]) : "v"(PW[HIST + i]), "s"(qv), "v"(c31));
+	}
+#pragma unroll
+	for (int jj = 1; jj < MAXORDER / 2 + 1; jj++) {
+		if ((uint32_t)(2 * jj) <= order) {
+			const int32_t qv = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)qf[jj]);
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				sum[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, PW[HIST + i - 2 * jj]), __builtin_bit_cast(fa_short2, qv), sum[i], false);
+		}
+	}
+	if (shift) {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			x[i] = (uint32_t)sum[i] >> shift;
+	} else {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			x[i] = (uint32_t)sum[i];
+	}
+}
+
+// The same with a tap per v_mad_i32_i24, for samples of up to 24 bits whose sums stay inside 32 bits.
+template <int HIST, int MAXORDER, typename Q>
+__device__ __forceinline__ void lpc_negres16_taps(const int32_t (&d)[HIST + FA_CHUNK], const Q &q, uint32_t order, uint32_t shift, uint32_t c31,
+                                                  uint32_t (&x)[FA_CHUNK])
+{
+	uint32_t sum[FA_CHUNK];   // unsigned: the chain passes 2^31 on purpose
+	const int32_t m2s = -(int32_t)(1u << shift);
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++)
+		sum[i] = (uint32_t)__mul24(m2s, d[HIST + i]) + c31;
+#pragma unroll
+	for (int j = 0; j < MAXORDER; j++) {
+		if ((uint32_t)j < order) {
+			const int32_t qj = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)q[j]);
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				sum[i] += (uint32_t)__mul24(qj, d[HIST + i - 1 - j]);
+		}
+	}
+	if (shift) {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			x[i] = sum[i] >> shift;
+	} else {
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			x[i] = sum[i];
 	}
 }
 

@@ -31,6 +31,7 @@ struct SrCand {
 	uint32_t pmax, pmin, psize, use32;
 	uint32_t fast;      // every |residual| of this candidate is below 2^27
 	uint32_t hdr_bits;  // subframe bits besides the residual
+	uint32_t sumq;      // an upper bound of the sum of the coefficients' magnitudes (exact for the fixed predictors)
 	uint32_t best_po, best_rbits, total_bits;
 };
 
@@ -85,6 +86,37 @@ __device__ __forceinline__ void accumulate_biased(const uint32_t (&db)[FA_CHUNK]
 	}
 }
 
+// The same from x[i] = B - residual (lpc_negres16_*): |residual| = |x - B| is one v_sad_u32.  The
+// rare paths take the chunk's position through an opaque copy, so that nothing derived from it is
+// computed ahead of the candidate loop and kept in registers across it.
+__device__ __forceinline__ void accumulate_negres(const uint32_t (&x)[FA_CHUNK], uint32_t B, uint64_t *gs, uint32_t base, uint32_t order,
+                                                  uint32_t bsf, uint32_t psize, bool quick, uint32_t quick_part)
+{
+	if (quick) {
+		uint32_t t32 = 0;
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			t32 = sad_u32(x[i], B, t32);
+		if (base < order) {
+			uint32_t b2 = base;
+			asm volatile("" : "+v"(b2));
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				if (b2 + i < order)
+					t32 -= abs32((int32_t)(B - x[i]));
+		}
+		atomicAdd((unsigned long long *)&gs[quick_part], (unsigned long long)t32);
+	} else {
+		uint32_t b2 = base;
+		asm volatile("" : "+v"(b2));
+		int32_t res[FA_CHUNK];
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			res[i] = (int32_t)(B - x[i]);
+		accumulate_chunk(res, gs, b2, order, bsf, psize);
+	}
+}
+
 // LDS carve-up, computed the same way on the host (for the size) and in the kernel.
 struct SrLayout {
 	uint32_t sums, stage, pbits, gc, best, ctl, cq, cqp, gp, lcand, allq, total;
@@ -111,7 +143,7 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 	L.ctl = o; o += 16 * 4;
 	L.cq = o; o += ncmax * qstride * 4;
 	o = (o + 15) & ~15u;
-	L.cqp = o; o += ncmax * ((qstride + 1) / 2) * 4;
+	L.cqp = o; o += ncmax * (qstride / 2 + 1) * 4;
 	o = (o + 15) & ~15u;
 	L.gp = o; o += ncmax * 8 * 4;
 	L.lcand = o; o += npre_cands * (uint32_t)sizeof(FaLpcCand);
@@ -153,10 +185,12 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
               uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps, unsigned long long sig_list, uint32_t nsel)
 {
 // debugging aid: the first time thread 0 passes point k, the shader clock goes to stamps[block][k]
-#define STAMP(k) do { if (stamps && threadIdx.x == 0 && first_pass) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(k) do { if (stamps && threadIdx.x == 0 && first_pass) stamps[(size_t)task * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 	bool first_pass = true;
 	constexpr int MAXORDER = HIST < FA_MAX_ORDER ? HIST : FA_MAX_ORDER;   // largest predictor order this kernel runs
-	constexpr int NQP = (MAXORDER + 1) / 2;
+	constexpr int NQP = (MAXORDER + 1) / 2;   // words of tap pairs (split form)
+	constexpr int NQF = MAXORDER / 2 + 1;     // words of the folded form: the sample's own tap comes first
+	constexpr int NQW = RES == SR_RES_DOT2 ? NQF : NQP;
 	constexpr uint32_t NIT = (ST_HP(HIST) + FA_TILE + FA_THREADS - 1) / FA_THREADS;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t ncoef_all = P.ncand * P.max_lpc_order;
@@ -169,13 +203,18 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 	FaPlan *best = (FaPlan *)(smem + L.best);
 	uint32_t *ctl = (uint32_t *)(smem + L.ctl);         // [0]=group size [1]=cursor [2]=winner [3]=rice2 flag
 	int32_t *cq = (int32_t *)(smem + L.cq);             // [group][MAXORDER] quantised coefficients
-	int32_t *cqp = (int32_t *)(smem + L.cqp);           // [group][NQP] the same, two 16-bit taps per word
-	uint32_t *gp = (uint32_t *)(smem + L.gp);           // [group][4] order, shift, psize, fast | mode << 1
+	int32_t *cqp = (int32_t *)(smem + L.cqp);           // [group][NQW] the same, two 16-bit taps per word (dot2: folded form, see lpc_negres16_dot2)
+	uint32_t *gp = (uint32_t *)(smem + L.gp);           // [group][4] order, shift, psize, fast | mode << 1 | slow << 3 | shift << 8 | (frame's - candidate's largest partition order) << 16
 	uint32_t *gq = gp + ncmax * 4;                      // [group][4] pmax | pmin << 8 | use32 << 16, order, seed
 	FaLpcCand *lcand = (FaLpcCand *)(smem + L.lcand);   // candidate slots fetched at entry
 	int32_t *allq = (int32_t *)(smem + L.allq);         // coefficients fetched at entry
 
-	const uint32_t f = blockIdx.x / nsel, s = (uint32_t)(sig_list >> (4 * (blockIdx.x % nsel))) & 15u;
+	// Workgroups go to the chip's eight dies in turn, each with an L2 of its own: the workgroups of one
+	// frame's signals, which read the same samples, are given indices that are equal modulo eight.
+	const uint32_t f = (blockIdx.x / (8 * nsel)) * 8 + (blockIdx.x & 7u);
+	if (f >= B.nframes)
+		return;
+	const uint32_t s = (uint32_t)(sig_list >> (4 * ((blockIdx.x % (8 * nsel)) >> 3))) & 15u;
 	const uint32_t task = f * P.nsignals + s;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
@@ -265,6 +304,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 				c.shift = 0;
 				c.mode = (uint32_t)lpc_mode(0, sbps);
 				c.hdr_bits = 0;
+				c.sumq = 0;
 				bool take = false;
 				if (my < 5) {
 					// fixed predictors (stream_encoder.c:3236-3287)
@@ -282,6 +322,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 						c.order = order;
 						c.seed = rice;
 						c.hdr_bits = hdr + order * sbps;
+						c.sumq = (1u << order) - 1u;   // 0, 1, 2+1, 3+3+1, 4+6+4+1
 						take = true;
 					}
 				} else if (my < total_cands) {
@@ -300,6 +341,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 						c.shift = lc.shift;
 						c.mode = (uint32_t)lpc_mode(lc.wide, sbps);
 						c.hdr_bits = hdr + 4 + 5 + lc.order * (lc.precision + sbps);
+						c.sumq = (uint32_t)lc.sumq32 << 5;
 						take = true;
 					}
 				}
@@ -352,29 +394,36 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		};
 		for (uint32_t e = tid; e < ng * MAXORDER; e += FA_THREADS)
 			cq[e] = coef(e / MAXORDER, e % MAXORDER);
-		for (uint32_t e = tid; e < ng * NQP; e += FA_THREADS) {
-			const uint32_t g = e / NQP, jj = e % NQP;
-			const uint32_t q0 = (uint32_t)coef(g, 2 * jj), q1 = (uint32_t)coef(g, 2 * jj + 1);
+		for (uint32_t e = tid; e < ng * NQW; e += FA_THREADS) {
+			const uint32_t g = e / NQW, jj = e % NQW;
+			uint32_t q0, q1;
+			if (RES == SR_RES_DOT2) {
+				// c[0] = -2^shift, c[m] = q[m - 1]
+				q0 = jj ? (uint32_t)coef(g, 2 * jj - 1) : 0u - (1u << (gc[g].shift & 15));
+				q1 = (uint32_t)coef(g, 2 * jj);
+			} else {
+				q0 = (uint32_t)coef(g, 2 * jj);
+				q1 = (uint32_t)coef(g, 2 * jj + 1);
+			}
 			cqp[e] = (int32_t)((q0 << 16) | (q1 & 0xffffu));
 		}
-		for (uint32_t e = tid; e < ng * 16; e += FA_THREADS)
-			pbits[e] = 0;
+		if (PF > 64)
+			for (uint32_t e = tid; e < ng * 16; e += FA_THREADS)
+				pbits[e] = 0;
 		if (tid >= 64 && tid - 64 < ng) {
 			const uint32_t g = tid - 64;
 			SrCand &c = gc[g];
 			// |prediction| <= (sum |q| * max |sample|) >> shift, |residual| <= |sample| + |prediction|
-			uint64_t sumq = 0;
-			for (uint32_t j = 0; j < c.order; j++)
-				sumq += abs32(coef(g, j));
+			const uint64_t sumq = c.sumq;
 			const uint64_t bound = (1ull << (sbps - 1)) + ((sumq << (sbps - 1)) >> c.shift) + 1;
 			// (a sum that wraps in 32 bits stays below 2^(31 - shift), which the bound covers too)
 			const uint32_t fast = ((RES != SR_RES_TAPS || c.mode == 0) && bound < (1ull << 27)) ? 1u : 0u;
 			c.fast = fast;
 			uint32_t slow = 0, sh = (uint32_t)c.shift;
-			if (RES == SR_RES_DOT2) {
-				// one wrapping 32-bit chain: exact for the 64-bit candidates while no sum can reach 2^31
-				slow = (c.mode == 2 && (sumq << (sbps - 1)) >= (1ull << 31)) ? 1u : 0u;
-			} else if (RES == SR_RES_SPLIT) {
+			if (RES != SR_RES_SPLIT) {
+				// the folded chain is exact while sum - sample * 2^shift stays inside 32 bits
+				slow = fa_fold_exact(sumq, (uint32_t)c.shift, sbps) ? 0u : 1u;
+			} else {
 				const uint32_t shf = (uint32_t)c.shift;
 				if (c.mode != 2)
 					sh = 12u | (shf << 16);
@@ -387,7 +436,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			gp[4 * g] = c.order;
 			gp[4 * g + 1] = sh;
 			gp[4 * g + 2] = c.psize;
-			gp[4 * g + 3] = fast | (c.mode << 1) | (slow << 3) | ((uint32_t)c.shift << 8);
+			gp[4 * g + 3] = fast | (c.mode << 1) | (slow << 3) | ((uint32_t)c.shift << 8) | ((frame_max_po - c.pmax) << 16);
 			gq[4 * g] = c.pmax | (c.pmin << 8) | (c.use32 << 16);
 			gq[4 * g + 1] = c.order;
 			gq[4 * g + 2] = c.seed;
@@ -443,50 +492,57 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			uint32_t part_psize = 0, part_of_chunk = 0;
 			// the next candidate's parameters and coefficients are fetched from LDS while the current
 			// one is computed; at the loop top they move to scalar registers
+			// the chunk's finest partition at the frame's largest partition order; a candidate whose own
+			// largest order is lower shifts it down (2^order divides the frame length)
+			const uint32_t part_finest = base / (bsf >> frame_max_po);
 			if (RES == SR_RES_DOT2) {
-				// samples and coefficients fit 16 bits: two taps per instruction
-				int32_t Pk[HIST + FA_CHUNK - 1];
+				// samples and coefficients fit 16 bits: two taps per instruction, residual folded into the chain
+				int32_t PW[HIST + FA_CHUNK];
+				PW[0] = (int32_t)((uint32_t)d[0] << 16);
 #pragma unroll
-				for (int k = 0; k < HIST + FA_CHUNK - 1; k++)
-					Pk[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k + 1], (uint32_t)d[k], 0x05040100u);
+				for (int k = 1; k < HIST + FA_CHUNK; k++)
+					PW[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k], (uint32_t)d[k - 1], 0x05040100u);
+				const uint32_t c31 = bias;
 				uint32_t nxp[4];
-				int32_t nxq[NQP];
+				int32_t nxq[NQF];
 #pragma unroll
 				for (int k = 0; k < 4; k++)
 					nxp[k] = gp[k];
 #pragma unroll
-				for (int k = 0; k < NQP; k++)
+				for (int k = 0; k < NQF; k++)
 					nxq[k] = cqp[k];
 #pragma nounroll
 				for (uint32_t g = 0; g < ng; g++) {
 					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
-					const int shift = (int)__builtin_amdgcn_readfirstlane(nxp[1]);
+					const uint32_t shift = __builtin_amdgcn_readfirstlane(nxp[1]);
 					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
 					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
 					const uint32_t fast = flags & 1u;
-					int32_t qs[NQP];
+					int32_t qs[NQF];
 #pragma unroll
-					for (int k = 0; k < NQP; k++)
+					for (int k = 0; k < NQF; k++)
 						qs[k] = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)nxq[k]);
 					if (g + 1 < ng) {
 #pragma unroll
 						for (int k = 0; k < 4; k++)
 							nxp[k] = gp[4 * (g + 1) + k];
 #pragma unroll
-						for (int k = 0; k < NQP; k++)
-							nxq[k] = cqp[(g + 1) * NQP + k];
+						for (int k = 0; k < NQF; k++)
+							nxq[k] = cqp[(g + 1) * NQF + k];
 					}
-					int32_t pred[FA_CHUNK];
-					if (!NARROW && (flags & 8u))
-						lpc_pred16_exact64<HIST, MAXORDER>([&](int k) -> int32_t { return (int32_t)(int16_t)(Pk[k] & 0xffff); }, qs, order, shift, pred);
-					else
-						lpc_pred16_dot2<HIST, MAXORDER>(Pk, qs, order, shift, pred);
-					if (psize != part_psize) {
-						part_psize = psize;
-						part_of_chunk = base / psize;
+					uint32_t x[FA_CHUNK], B;
+					if (flags & 8u) {
+						// exact 64-bit taps; sample k of the window is the high half of PW[k], coefficient j is c[j + 1]
+						B = bias;
+						lpc_negres16_exact64<HIST, MAXORDER>([&](int k) -> int32_t { return PW[k] >> 16; },
+						                                     [&](int j) -> int32_t { return packed_coef(qs, j + 1); }, order, (int)shift,
+						                                     ((flags >> 1) & 3u) != 2u, x);
+					} else {
+						lpc_negres16_dot2<HIST, MAXORDER>(PW, qs, order, shift, c31, x);
+						B = bias >> shift;
 					}
-					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
-					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
+					accumulate_negres(x, B, sums + (size_t)g * 2 * PF, base, order, bsf, psize, fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0,
+					                  part_finest >> ((flags >> 16) & 15u));
 				}
 			} else if (RES == SR_RES_SPLIT) {
 				// wider samples in two 16-bit halves: two chains of two taps per instruction
@@ -530,7 +586,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 						auto getd = [&](int k) -> int32_t {
 							return (int32_t)(((uint32_t)(int32_t)(int16_t)((uint32_t)Ph[k] & 0xffff) << 12) | ((uint32_t)Pl[k] & 0xfffu));
 						};
-						lpc_pred16_exact64<HIST, MAXORDER>(getd, qs, order, (int)(flags >> 8), pred);
+						lpc_pred16_exact64<HIST, MAXORDER>(getd, [&](int j) -> int32_t { return packed_coef(qs, j); }, order, (int)((flags >> 8) & 0xff), false, pred);
 					} else
 						lpc_pred16_split<HIST, MAXORDER>(Ph, Pl, qs, order, shc & 0xff, (shc >> 8) & 0xff, shc >> 16, pred);
 					if (psize != part_psize) {
@@ -541,6 +597,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
 				}
 			} else {
+				static_assert(RES != SR_RES_TAPS || NARROW, "the tap-at-a-time form is compiled for 32-bit sums only");
+				const uint32_t c31 = bias;
 				uint32_t nxp[4];
 				int32_t nxq[MAXORDER];
 #pragma unroll
@@ -552,11 +610,10 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 #pragma nounroll
 				for (uint32_t g = 0; g < ng; g++) {
 					const uint32_t order = __builtin_amdgcn_readfirstlane(nxp[0]);
-					const int shift = (int)__builtin_amdgcn_readfirstlane(nxp[1]);
+					const uint32_t shift = __builtin_amdgcn_readfirstlane(nxp[1]);
 					const uint32_t psize = __builtin_amdgcn_readfirstlane(nxp[2]);
 					const uint32_t flags = __builtin_amdgcn_readfirstlane(nxp[3]);
 					const uint32_t fast = flags & 1u;
-					const int mode = (int)((flags >> 1) & 3u);
 					int32_t qs[MAXORDER];
 #pragma unroll
 					for (int k = 0; k < MAXORDER; k++)
@@ -569,14 +626,21 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 						for (int k = 0; k < MAXORDER; k++)
 							nxq[k] = cq[(g + 1) * MAXORDER + k];
 					}
-					int32_t pred[FA_CHUNK];
-					lpc_pred16_any<HIST, NARROW>(d, qs, order, shift, mode, pred);
-					if (psize != part_psize) {
-						part_psize = psize;
-						part_of_chunk = base / psize;
+					uint32_t x[FA_CHUNK], B;
+					if (flags & 8u) {
+						// the wrapping 32-bit sum as it stands
+						int32_t pred[FA_CHUNK];
+						lpc_pred16_taps<HIST, MAXORDER, 0>(d, qs, order, (int)shift, pred);
+						B = bias;
+#pragma unroll
+						for (int i = 0; i < FA_CHUNK; i++)
+							x[i] = B - ((uint32_t)d[HIST + i] - (uint32_t)pred[i]);
+					} else {
+						lpc_negres16_taps<HIST, MAXORDER>(d, qs, order, shift, c31, x);
+						B = bias >> shift;
 					}
-					accumulate_biased(db, pred, sums + (size_t)g * 2 * PF, base, order, bsf, psize,
-					                  fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0, bias, part_of_chunk);
+					accumulate_negres(x, B, sums + (size_t)g * 2 * PF, base, order, bsf, psize, fast && chunk_inside && (psize & (FA_CHUNK - 1)) == 0,
+					                  part_finest >> ((flags >> 16) & 15u));
 				}
 			}
 		}
@@ -591,126 +655,143 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 
 		const uint32_t fpo = frame_max_po;
 		if (PF <= 64) {
-			// ---- precompute_partition_info_sums_ (stream_encoder.c:3774) and set_partitioned_rice_
-			// (stream_encoder.c:3943) with a wave per candidate: lane l holds finest sum l, a butterfly
-			// of lane exchanges gives every lane the sum of its enclosing partition at each coarser
-			// level; lane l then prices the finest partition l and one coarser one (the lanes whose
-			// index has t trailing zeros share out the partitions t + 1 levels up), so nothing waits
-			// on LDS between the levels. ----
+			// ---- precompute_partition_info_sums_ (stream_encoder.c:3774), set_partitioned_rice_
+			// (stream_encoder.c:3943) and the scan of find_best_partition_order_ (stream_encoder.c:3700-3729)
+			// with a wave per candidate and nothing but lane exchanges between the steps.  Lane l holds
+			// finest sum l.  Group sums of 2, 4, 8 and 16 lanes come from four cross-lane adds (quad
+			// permutes, then the mirror patterns: the values are already uniform inside the smaller group),
+			// those of 32 and 64 from the four row sums read into scalars.  The lane whose index has t
+			// trailing zeros then holds the sum of the partition t + 1 levels up that starts at it; one
+			// permute moves these into level order (level max-1 in lanes 0.., then max-2, ..: the order they
+			// have behind the finest sums in LDS), so that lane c prices finest partition c and coarser
+			// item c, and the bits of a level are again sums over aligned lane groups. ----
 			const uint32_t wv = tid >> 6, ln = tid & 63;
 			const uint32_t tz = ln ? (uint32_t)__builtin_ctz(ln) : 0u;
-			auto price64 = [&](uint32_t g) {
-				const uint4 q = *(const uint4 *)(gq + 4 * g);
-				const uint32_t pm = q.x & 0xff, pmn = (q.x >> 8) & 0xff;
-				uint64_t *gs = sums + (size_t)g * 2 * PF;
-				const bool mine = ln < (1u << pm);
-				uint64_t v[7];
-				v[0] = mine ? gs[ln] : 0ull;
-				if (q.x >> 16) {
-					// the reference's accumulator is 32 bits wide here (stream_encoder.c:3803-3833)
-					v[0] &= 0xffffffffull;
-					if (mine)
-						gs[ln] = v[0];
-				}
-#pragma unroll
-				for (int j = 0; j < 6; j++)
-					v[j + 1] = v[j] + (uint64_t)__shfl_xor((unsigned long long)v[j], 1 << j, 64);
-				// the coarser partition this lane prices: level pm - 1 - tz, the one enclosing lane ln
-				uint64_t sc = v[1];
-#pragma unroll
-				for (int j = 1; j < 6; j++)
-					sc = tz == (uint32_t)j ? v[j + 1] : sc;
-				const int lc = (int)pm - 1 - (int)tz;
-				const bool have_c = mine && ln != 0 && lc >= (int)pmn;
-				const uint32_t poc = have_c ? (uint32_t)lc : 0u;
-				const uint32_t pc = ln >> (tz + 1);
-				const uint32_t nf = (bsf >> pm) - (ln == 0 ? q.y : 0u);
-				const uint32_t nc = (bsf >> poc) - (pc == 0 ? q.y : 0u);
-				const bool narrow = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v[6] >> 32)) == 0;
-				uint32_t bf, bc;
-				if (narrow) {
-					const uint32_t kf = (pm == 0) ? q.z : rice_k_from_sum32((uint32_t)v[0], nf, P.rice_limit);
-					const uint32_t kc = (poc == 0) ? q.z : rice_k_from_sum32((uint32_t)sc, nc, P.rice_limit);
-					bf = rice_bits_estimate32(kf, nf, (uint32_t)v[0]);
-					bc = rice_bits_estimate32(kc, nc, (uint32_t)sc);
-				} else {
-					const uint32_t kf = (pm == 0) ? q.z : rice_k_from_sum(v[0], nf, P.rice_limit);
-					const uint32_t kc = (poc == 0) ? q.z : rice_k_from_sum(sc, nc, P.rice_limit);
-					bf = rice_bits_estimate(kf, nf, v[0]);
-					bc = rice_bits_estimate(kc, nc, sc);
-				}
-				if (mine)
-					atomicAdd(&pbits[g * 16 + pm], bf);
-				if (have_c) {
-					atomicAdd(&pbits[g * 16 + poc], bc);
-					gs[(2u << pm) - (2u << poc) + pc] = sc;   // the winner's parameters are derived from these
-				}
-			};
-			// Two candidates at a time, so that their chains of lane exchanges overlap; in 32-bit arithmetic
-			// when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32), which is always
-			// so for streams of up to 16 bits.
+#define DPP_ADD(x, ctrl) ((x) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, true))
+#define DPP_PAIRS 0xB1   /* quad_perm [1,0,3,2] */
+#define DPP_QUADS 0x4E   /* quad_perm [2,3,0,1] */
+#define DPP_EIGHTS 0x141 /* row_half_mirror */
+#define DPP_ROWS 0x140   /* row_mirror */
 			for (uint32_t g0 = wv; g0 < ng; g0 += 2 * (FA_THREADS / 64)) {
 				const uint32_t gb = g0 + FA_THREADS / 64;
 				const bool two = gb < ng;
 				const uint32_t gi[2] = {g0, two ? gb : g0};
 				uint4 q[2];
 				uint64_t f64[2];
-				bool mine[2];
+				uint32_t hdrb[2];
 #pragma unroll
 				for (int c = 0; c < 2; c++) {
 					q[c] = *(const uint4 *)(gq + 4 * gi[c]);
-					mine[c] = ln < (1u << (q[c].x & 0xff));
-					f64[c] = mine[c] ? sums[(size_t)gi[c] * 2 * PF + ln] : 0ull;
+					hdrb[c] = gc[gi[c]].hdr_bits;
+					f64[c] = ln < (1u << (q[c].x & 0xff)) ? sums[(size_t)gi[c] * 2 * PF + ln] : 0ull;
 					if (q[c].x >> 16)
 						f64[c] &= 0xffffffffull;   // the reference's 32-bit accumulator (stream_encoder.c:3803-3833)
 				}
-				if (!__all(((f64[0] | f64[1]) >> 26) == 0)) {
-					price64(g0);
-					if (two)
-						price64(gb);
-					continue;
-				}
-				uint32_t v[2][7];
-#pragma unroll
-				for (int c = 0; c < 2; c++)
-					v[c][0] = (uint32_t)f64[c];
-#pragma unroll
-				for (int j = 0; j < 6; j++)
-#pragma unroll
-					for (int c = 0; c < 2; c++)
-						v[c][j + 1] = v[c][j] + (uint32_t)__shfl_xor((int)v[c][j], 1 << j, 64);
+				// 32-bit arithmetic when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32),
+				// which is always so for streams of up to 16 bits
+				const bool narrow = __all(((f64[0] | f64[1]) >> 26) == 0);
 #pragma unroll
 				for (int c = 0; c < 2; c++) {
 					if (c == 1 && !two)
 						break;
 					const uint32_t g = gi[c];
-					const uint32_t pm = q[c].x & 0xff, pmn = (q[c].x >> 8) & 0xff;
+					const uint32_t pm = __builtin_amdgcn_readfirstlane(q[c].x & 0xff), pmn = __builtin_amdgcn_readfirstlane((q[c].x >> 8) & 0xff);
+					const uint32_t use32 = __builtin_amdgcn_readfirstlane(q[c].x >> 16);
+					const uint32_t order = __builtin_amdgcn_readfirstlane(q[c].y), seed = __builtin_amdgcn_readfirstlane(q[c].z);
 					uint64_t *gs = sums + (size_t)g * 2 * PF;
-					uint32_t sc = v[c][1];
+					const bool mine = ln < (1u << pm);
+					// coarser item of this lane: with x = the zero bits of ln below bit pm, its level is the
+					// highest one of them, its partition the bits of ln below that
+					const uint32_t zeros = ~ln & ((1u << pm) - 1u);
+					const uint32_t poc = zeros ? ilog2u(zeros) : 0u;
+					const uint32_t pc = ln & ((1u << poc) - 1u);
+					const bool have_c = mine && zeros != 0 && poc >= pmn;
+					const uint32_t src = (2u * pc + 1u) << ((pm - 1u - poc) & 31u);   // the lane that holds its sum after the exchanges
+					const uint32_t nf = (bsf >> pm) - (ln == 0 ? order : 0u);
+					const uint32_t nc = (bsf >> poc) - (pc == 0 ? order : 0u);
+					uint32_t bf, bc;
+					if (narrow) {
+						uint32_t v[7];
+						v[0] = (uint32_t)f64[c];
+						v[1] = DPP_ADD(v[0], DPP_PAIRS);
+						v[2] = DPP_ADD(v[1], DPP_QUADS);
+						v[3] = DPP_ADD(v[2], DPP_EIGHTS);
+						v[4] = DPP_ADD(v[3], DPP_ROWS);
+						const uint32_t r0 = __builtin_amdgcn_readlane(v[4], 0), r1 = __builtin_amdgcn_readlane(v[4], 16);
+						const uint32_t r2 = __builtin_amdgcn_readlane(v[4], 32), r3 = __builtin_amdgcn_readlane(v[4], 48);
+						v[5] = ln < 32 ? r0 + r1 : r2 + r3;
+						v[6] = r0 + r1 + r2 + r3;
+						uint32_t up = v[1];
 #pragma unroll
-					for (int j = 1; j < 6; j++)
-						sc = tz == (uint32_t)j ? v[c][j + 1] : sc;
-					const int lc = (int)pm - 1 - (int)tz;
-					const bool have_c = mine[c] && ln != 0 && lc >= (int)pmn;
-					const uint32_t poc = have_c ? (uint32_t)lc : 0u;
-					const uint32_t pc = ln >> (tz + 1);
-					const uint32_t nf = (bsf >> pm) - (ln == 0 ? q[c].y : 0u);
-					const uint32_t nc = (bsf >> poc) - (pc == 0 ? q[c].y : 0u);
-					const uint32_t kf = (pm == 0) ? q[c].z : rice_k_from_sum32(v[c][0], nf, P.rice_limit);
-					const uint32_t kc = (poc == 0) ? q[c].z : rice_k_from_sum32(sc, nc, P.rice_limit);
-					const uint32_t bf = rice_bits_estimate32(kf, nf, v[c][0]);
-					const uint32_t bc = rice_bits_estimate32(kc, nc, sc);
-					if (mine[c]) {
-						atomicAdd(&pbits[g * 16 + pm], bf);
-						if (q[c].x >> 16)
-							gs[ln] = v[c][0];
+						for (int j = 1; j < 6; j++)
+							up = tz == (uint32_t)j ? v[j + 1] : up;
+						const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)up);
+						const uint32_t kf = (pm == 0) ? seed : rice_k_from_sum32(v[0], nf, P.rice_limit);
+						const uint32_t kc = (poc == 0) ? seed : rice_k_from_sum32(sc, nc, P.rice_limit);
+						bf = rice_bits_estimate32(kf, nf, v[0]);
+						bc = rice_bits_estimate32(kc, nc, sc);
+						if (mine && use32)
+							gs[ln] = v[0];
+						if (have_c)
+							gs[(1u << pm) + ln] = sc;   // the winner's parameters are derived from these
+					} else {
+						uint64_t v[7];
+						v[0] = f64[c];
+#pragma unroll
+						for (int j = 0; j < 6; j++)
+							v[j + 1] = v[j] + (uint64_t)__shfl_xor((unsigned long long)v[j], 1 << j, 64);
+						uint64_t up = v[1];
+#pragma unroll
+						for (int j = 1; j < 6; j++)
+							up = tz == (uint32_t)j ? v[j + 1] : up;
+						const uint64_t sc = (uint64_t)__shfl((unsigned long long)up, (int)src, 64);
+						const uint32_t kf = (pm == 0) ? seed : rice_k_from_sum(v[0], nf, P.rice_limit);
+						const uint32_t kc = (poc == 0) ? seed : rice_k_from_sum(sc, nc, P.rice_limit);
+						bf = rice_bits_estimate(kf, nf, v[0]);
+						bc = rice_bits_estimate(kc, nc, sc);
+						if (mine && use32)
+							gs[ln] = v[0];
+						if (have_c)
+							gs[(1u << pm) + ln] = sc;
 					}
-					if (have_c) {
-						atomicAdd(&pbits[g * 16 + poc], bc);
-						gs[(2u << pm) - (2u << poc) + pc] = sc;   // the winner's parameters are derived from these
+					// bits per level: the finest one is the sum over the wave, level po that of the 2^po lanes
+					// from lane 2^pm - 2^(po+1) on
+					uint32_t wf[5], wc[5];
+					wf[0] = mine ? bf : 0u;
+					wc[0] = have_c ? bc : 0u;
+					wf[1] = DPP_ADD(wf[0], DPP_PAIRS);
+					wc[1] = DPP_ADD(wc[0], DPP_PAIRS);
+					wf[2] = DPP_ADD(wf[1], DPP_QUADS);
+					wc[2] = DPP_ADD(wc[1], DPP_QUADS);
+					wf[3] = DPP_ADD(wf[2], DPP_EIGHTS);
+					wc[3] = DPP_ADD(wc[2], DPP_EIGHTS);
+					wf[4] = DPP_ADD(wf[3], DPP_ROWS);
+					wc[4] = DPP_ADD(wc[3], DPP_ROWS);
+					// find_best_partition_order_: from the largest order down, a smaller one must be strictly better
+					uint32_t bestb = 6u + __builtin_amdgcn_readlane(wf[4], 0) + __builtin_amdgcn_readlane(wf[4], 16) + __builtin_amdgcn_readlane(wf[4], 32) +
+					                 __builtin_amdgcn_readlane(wf[4], 48);
+					uint32_t bestpo = pm;
+#pragma unroll
+					for (int po = 5; po >= 0; po--) {
+						if ((uint32_t)po < pm && (uint32_t)po >= pmn) {
+							const uint32_t at = (1u << pm) - (2u << po);
+							const uint32_t lb = po == 5 ? __builtin_amdgcn_readlane(wc[4], 0) + __builtin_amdgcn_readlane(wc[4], 16)
+							                            : __builtin_amdgcn_readlane(wc[po], at);
+							if (6u + lb < bestb) {
+								bestb = 6u + lb;
+								bestpo = (uint32_t)po;
+							}
+						}
+					}
+					if (ln == 0) {
+						SrCand &cd = gc[g];
+						cd.best_po = bestpo;
+						cd.best_rbits = bestb;
+						cd.total_bits = hdrb[c] + bestb;
 					}
 				}
 			}
+#undef DPP_ADD
 		} else {
 		// ---- precompute_partition_info_sums_ (stream_encoder.c:3774): every finest sum, truncated to
 		// 32 bits where the reference's accumulator is that narrow (:3803-3833), is added into the
@@ -760,18 +841,20 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 			uint32_t total = 0xffffffffu;
 			if (tid < ng) {
 				SrCand &c = gc[tid];
-				uint32_t bestb = 0, bestpo = 0;
-				for (int po = (int)c.pmax; po >= (int)c.pmin; po--) {
-					const uint32_t bits = 2 + 4 + pbits[tid * 16 + po];
-					if (bestb == 0 || bits < bestb) {
-						bestb = bits;
-						bestpo = (uint32_t)po;
+				if (PF > 64) {
+					uint32_t bestb = 0, bestpo = 0;
+					for (int po = (int)c.pmax; po >= (int)c.pmin; po--) {
+						const uint32_t bits = 2 + 4 + pbits[tid * 16 + po];
+						if (bestb == 0 || bits < bestb) {
+							bestb = bits;
+							bestpo = (uint32_t)po;
+						}
 					}
+					c.best_po = bestpo;
+					c.best_rbits = bestb;
+					c.total_bits = c.hdr_bits + bestb;
 				}
-				c.best_po = bestpo;
-				c.best_rbits = bestb;
-				total = c.hdr_bits + bestb;
-				c.total_bits = total;
+				total = c.total_bits;
 			}
 			uint32_t mn = total;
 #pragma unroll
@@ -882,7 +965,7 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 			list_taps |= (unsigned long long)sg << (4 * n_taps++);
 	}
 #define SEARCH_LAUNCH1(H, N, PR, R, LIST, NSEL) \
-	hipLaunchKernelGGL((k_search<H, N, PR, R>), dim3(B.nframes * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
+	hipLaunchKernelGGL((k_search<H, N, PR, R>), dim3((B.nframes + 7) / 8 * 8 * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
 	                   stamps, LIST, NSEL)
 	// the signals too wide for one 16-bit lane: a tap per instruction while 32-bit sums of 24-bit
 	// samples are all the stream can need, the split form otherwise

@@ -61,7 +61,7 @@ struct FaLpcCand {
 	int8_t  shift;
 	uint8_t rice;                 // Rice parameter seed used at partition order 0
 	uint8_t wide;                 // 64-bit accumulation in the residual
-	uint8_t pad[2];
+	uint16_t sumq32;              // sum of the coefficients' magnitudes, in units of 32, rounded up
 };
 
 // What the model search chose for one (frame, signal).
