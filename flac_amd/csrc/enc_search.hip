@@ -233,28 +233,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 #pragma unroll
 	for (uint32_t k = 0; k < SR_PRE_COEFS / FA_THREADS; k++)
 		pre_q[k] = (tid + k * FA_THREADS < npre_coefs) ? my_coefs[tid + k * FA_THREADS] : 0;
-	// 16-bit stereo in whole chunks: a thread's window of HIST + 16 wide samples is HIST / 4 + 4 aligned
-	// 16-byte loads straight into registers, and the signal is formed there; nothing is staged in LDS.
-	// (Positions before the frame read the frame's first samples instead: only predictions of warm-up
-	// samples use them, and those are taken back out of the sums.)
-	constexpr uint32_t NRAW = (HIST + FA_CHUNK) / 4;
-	const bool direct = PAIRS && (bsf & 15u) == 0 && (P.blocksize & 3u) == 0 && ((uintptr_t)pcm & 15u) == 0;
-	uint4 raw[NRAW];
-	auto load_raw = [&](uint32_t tile_base) {
-		const uint32_t base = tile_base + threadIdx.x * FA_CHUNK;
-		const uint4 *src = (const uint4 *)((const uint32_t *)pcm + frame_start);
-#pragma unroll
-		for (uint32_t k = 0; k < NRAW; k++) {
-			int32_t at = (int32_t)base - HIST + 4 * (int32_t)k;
-			at = (at < 0 || base >= bsf) ? 0 : at;
-			raw[k] = src[(uint32_t)at >> 2];
-		}
-	};
 	int32_t tile_v[NIT];
-	if (direct)
-		load_raw(0);
-	else
-		stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, 0);
+	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, 0);
 	const FaSubStat st = stats[task];
 	const uint32_t sbps = st.bps, wasted = st.wasted;
 	const uint32_t hdr = 8 + wasted;
@@ -294,8 +274,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		}
 		ctl[1] = 0;
 	}
-	if (!direct)
-		stage_store<HIST>(stage, tile_v, bsf, wasted, 0);
+	stage_store<HIST>(stage, tile_v, bsf, wasted, 0);
 	if (tid < npre_cands)
 		lcand[tid] = pre_c;
 #pragma unroll
@@ -475,55 +454,28 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 					sums[e] = 0;
 			}
 		};
-		if (!alias || direct)
+		if (!alias)
 			clear_sums();
 		STAMP(3);
 
 		// ---- residuals of every candidate of the group, tile by tile, all in registers ----
 		for (uint32_t tile = 0; tile < ntiles; tile++) {
+			if (!(tile == 0 && staged)) {
+				__syncthreads();
+				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
+			}
+			__syncthreads();
+			staged = false;
 			const uint32_t base = tile * FA_TILE + tid * FA_CHUNK;
 			const bool have = base < bsf;
 			int32_t d[HIST + FA_CHUNK];
-			if (direct) {
-				if (!(tile == 0 && staged))
-					load_raw(tile * FA_TILE);
-				staged = false;
-				if (tile == 0)
-					__syncthreads();   // the group's tables are written, its sums cleared
-				// left / right / mid / side from the packed words (stream_encoder.c:1968-2100 forms mid and side the same way)
-				auto word = [&](int k) -> uint32_t { return k % 4 == 0 ? raw[k / 4].x : k % 4 == 1 ? raw[k / 4].y : k % 4 == 2 ? raw[k / 4].z : raw[k / 4].w; };
-				if (s == 0) {
-#pragma unroll
-					for (int k = 0; k < HIST + FA_CHUNK; k++)
-						d[k] = (int32_t)(int16_t)(word(k) & 0xffff) >> wasted;
-				} else if (s == 1) {
-#pragma unroll
-					for (int k = 0; k < HIST + FA_CHUNK; k++)
-						d[k] = ((int32_t)word(k) >> 16) >> wasted;
-				} else if (s == 2) {
-#pragma unroll
-					for (int k = 0; k < HIST + FA_CHUNK; k++)
-						d[k] = (((int32_t)(int16_t)(word(k) & 0xffff) + ((int32_t)word(k) >> 16)) >> 1) >> wasted;
-				} else {
-#pragma unroll
-					for (int k = 0; k < HIST + FA_CHUNK; k++)
-						d[k] = ((int32_t)(int16_t)(word(k) & 0xffff) - ((int32_t)word(k) >> 16)) >> wasted;
-				}
-			} else {
-				if (!(tile == 0 && staged)) {
-					__syncthreads();
-					stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
-				}
+			if (have)
+				load_chunk_lds<HIST>(d, stage);
+			if (alias) {
+				// the sums take over the stage area once every thread holds its samples
 				__syncthreads();
-				staged = false;
-				if (have)
-					load_chunk_lds<HIST>(d, stage);
-				if (alias) {
-					// the sums take over the stage area once every thread holds its samples
-					__syncthreads();
-					clear_sums();
-					__syncthreads();
-				}
+				clear_sums();
+				__syncthreads();
 			}
 			STAMP(4);
 			if (!have)
