@@ -227,7 +227,7 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	ALLOC(e->stats, sizeof(FaSubStat) * F * S);
 	ALLOC(e->autoc, sizeof(float) * F * S * P.napod * (FA_MAX_ORDER + 1));
 	ALLOC(e->cands, sizeof(FaLpcCand) * F * S * P.ncand);
-	ALLOC(e->coefs, sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order);
+	ALLOC(e->coefs, sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order + 64);   // slack: the wave search reads twelve coefficients per slot whatever the order
 	ALLOC(e->plans, sizeof(FaPlan) * F * S);
 	ALLOC(e->assign, sizeof(uint32_t) * F);
 	ALLOC(e->slots, (size_t)P.slot_bytes * F + 64);
@@ -538,7 +538,7 @@ StaticLayout static_layout(const FaEncParams &P, size_t F)
 	L.stats = take(sizeof(FaSubStat) * F * S);
 	L.autoc = take(sizeof(float) * F * S * P.napod * (FA_MAX_ORDER + 1));
 	L.cands = take(sizeof(FaLpcCand) * F * S * P.ncand);
-	L.coefs = take(sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order);
+	L.coefs = take(sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order + 64);
 	L.plans = take(sizeof(FaPlan) * F * S);
 	L.assign = take(sizeof(uint32_t) * F);
 	L.slots = take((size_t)P.slot_bytes * F + 64);

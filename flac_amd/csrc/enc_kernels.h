@@ -14,6 +14,11 @@ void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stat
                    hipStream_t st);
 void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
                       const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st);
+// the wave-per-subframe form of the search (enc_search_wave.hip) for the listed signals of every frame
+bool fa_search_wave_eligible(const FaEncParams &P);
+void fa_launch_search_wave(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
+                           const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, unsigned long long wide_list, uint32_t nwide,
+                           hipStream_t st);
 void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st);
 void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
                     uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st);

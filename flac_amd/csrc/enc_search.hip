@@ -1,6 +1,9 @@
 // FLAC frame encoder kernels for gfx950 (MI355X), part 2: the model search.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "enc_common.h"
 #include "enc_kernels.h"
 
@@ -182,7 +185,7 @@ __host__ __device__ inline SrLayout sr_layout(uint32_t sum_bytes, uint32_t stage
 template <int HIST, bool NARROW, bool PAIRS, int RES>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(SR_WAVES(HIST, RES), SR_WAVES(HIST, RES))))
 void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands, const int32_t *coefs, FaPlan *plans,
-              uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps, unsigned long long sig_list, uint32_t nsel)
+              uint32_t sum_bytes, uint32_t alias, uint32_t ncmax, unsigned long long *stamps, unsigned long long sig_list, uint32_t nsel, uint32_t frame0)
 {
 // debugging aid: the first time thread 0 passes point k, the shader clock goes to stamps[block][k]
 #define STAMP(k) do { if (stamps && threadIdx.x == 0 && first_pass) stamps[(size_t)task * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -211,7 +214,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 
 	// Workgroups go to the chip's eight dies in turn, each with an L2 of its own: the workgroups of one
 	// frame's signals, which read the same samples, are given indices that are equal modulo eight.
-	const uint32_t f = (blockIdx.x / (8 * nsel)) * 8 + (blockIdx.x & 7u);
+	// (frames below frame0 are not this launch's)
+	const uint32_t f = frame0 + (blockIdx.x / (8 * nsel)) * 8 + (blockIdx.x & 7u);
 	if (f >= B.nframes)
 		return;
 	const uint32_t s = (uint32_t)(sig_list >> (4 * ((blockIdx.x % (8 * nsel)) >> 3))) & 15u;
@@ -921,6 +925,8 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 
 // LDS for the finest-partition sums: room for every candidate of a subframe in one group when
 // that fits
+static inline uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
 static uint32_t search_sum_bytes(const FaEncParams &P, uint32_t ncmax)
 {
 	uint32_t po = 0;
@@ -964,22 +970,54 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 		else
 			list_taps |= (unsigned long long)sg << (4 * n_taps++);
 	}
-#define SEARCH_LAUNCH1(H, N, PR, R, LIST, NSEL) \
-	hipLaunchKernelGGL((k_search<H, N, PR, R>), dim3((B.nframes + 7) / 8 * 8 * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, sum_bytes, alias, ncmax, \
-	                   stamps, LIST, NSEL)
+	// Streams with blocks of 4096 samples go to the wave-per-subframe form where it applies (FLAC_AMD_SEARCH=generic
+	// keeps every signal on the workgroup form, for comparisons): every signal when the stream needs 32-bit sums
+	// only, the signals of up to 16 bits otherwise.  first[R]: the first frame the workgroup form still has to do.
+	const bool narrow = fa_narrow_only(P);
+	uint32_t first_dot2 = 0, first_taps = 0;
+	{
+		const char *mode = getenv("FLAC_AMD_SEARCH");
+		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
+		if (!generic_only && fa_search_wave_eligible(P)) {
+			unsigned long long wl = 0, wide = 0;
+			uint32_t wn = 0, nwide = 0, left = 0;
+			for (uint32_t sg = 0; sg < P.nsignals; sg++) {
+				const uint32_t width = P.bps + ((P.do_ms && sg == P.channels + 1) ? 1u : 0u);
+				if (width <= 16 || narrow) {
+					wl |= (unsigned long long)sg << (4 * wn++);
+					if (width > 16)
+						wide |= (unsigned long long)sg << (4 * nwide++);
+				} else
+					left++;
+			}
+			// (the two lists of the workgroup form are split by the same widths when it has a two-taps form at all)
+			if (wn && (left == 0 || hist >= 12)) {
+				fa_launch_search_wave(P, B, pcm, stats, cands, coefs, plans, wl, wn, wide, nwide, st);
+				if (left == 0)
+					first_dot2 = first_taps = B.nframes;
+				else
+					first_dot2 = B.nframes;
+			}
+		}
+	}
+#define SEARCH_LAUNCH1(H, N, PR, R, LIST, NSEL, FIRST) \
+	do { \
+		if ((FIRST) < B.nframes) \
+			hipLaunchKernelGGL((k_search<H, N, PR, R>), dim3((B.nframes - (FIRST) + 7) / 8 * 8 * (NSEL)), block, lds, st, P, B, pcm, stats, cands, coefs, plans, \
+			                   sum_bytes, alias, ncmax, stamps, LIST, NSEL, FIRST); \
+	} while (0)
 	// the signals too wide for one 16-bit lane: a tap per instruction while 32-bit sums of 24-bit
 	// samples are all the stream can need, the split form otherwise
 #define SEARCH_LAUNCH(H, N) \
 	do { \
 		if (B.pairs) { \
-			if (n_dot2) SEARCH_LAUNCH1(H, N, true, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2); \
-			if (n_taps) SEARCH_LAUNCH1(H, N, true, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps); \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, true, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2, first_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, true, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps, first_taps); \
 		} else { \
-			if (n_dot2) SEARCH_LAUNCH1(H, N, false, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2); \
-			if (n_taps) SEARCH_LAUNCH1(H, N, false, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps); \
+			if (n_dot2) SEARCH_LAUNCH1(H, N, false, (H >= 12 ? SR_RES_DOT2 : SR_RES_TAPS), list_dot2, n_dot2, first_dot2); \
+			if (n_taps) SEARCH_LAUNCH1(H, N, false, (N ? SR_RES_TAPS : SR_RES_SPLIT), list_taps, n_taps, first_taps); \
 		} \
 	} while (0)
-	const bool narrow = fa_narrow_only(P);
 	switch (hist) {
 	case 4: SEARCH_LAUNCH(4, true); break;
 	case 12: if (narrow) SEARCH_LAUNCH(12, true); else SEARCH_LAUNCH(12, false); break;

@@ -1,0 +1,603 @@
+// FLAC frame encoder kernels for gfx950 (MI355X): the model search with a wave per subframe.
+#include <hip/hip_runtime.h>
+
+#include "enc_common.h"
+#include "enc_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// k_search_wave: process_subframe_ (stream_encoder.c:3164) for one (frame, signal) of a stream with
+// blocks of 4096 samples, run by ONE wave that never waits for another.
+//
+// Lane l owns samples [64 l, 64 l + 64) of the frame and keeps them, with twelve samples of history,
+// in registers for the whole search.  With at most 2^6 Rice partitions in a frame a lane's samples
+// never straddle a partition, so the |residual| sum of a candidate's finest partitions
+// (precompute_partition_info_sums_, stream_encoder.c:3774) is one register per lane: no atomics, no
+// shared memory, and it is already in the layout the pricing step (set_partitioned_rice_,
+// stream_encoder.c:3943) wants, lane l holding finest sum l.  The candidates come one after the other
+// in the reference's trial order; their parameters and coefficients are the same in every lane and
+// live in scalar registers, loaded with scalar loads.  Four such waves share a SIMD and fill each
+// other's stalls; nothing in the kernel is a barrier between waves.
+// ---------------------------------------------------------------------------------------------
+#define SW_N 64                  // samples per lane
+#define SW_HIST 12               // history in front of them = largest predictor order
+#define SW_W (SW_HIST + SW_N)
+#define SW_ROW 68                // LDS words per staged row of 64 samples (four words of padding)
+#define SW_NQF (SW_HIST / 2 + 1) // words of the folded two-taps form (see lpc_negres16_dot2)
+
+// Sixteen samples' sums are finished (shifted, added up) before the next sixteen start: the optimiser,
+// left alone, sinks every shift and add to the end of the candidate, keeps all 64 chains alive until
+// then and runs out of registers.  An empty volatile statement that "uses" the running sum pins them.
+#define SW_FENCE() asm volatile("" : "+v"(t))
+
+
+// x[i] = B - residual for samples OFF .. OFF + 15 of the lane's run, two taps per v_dot2_i32_i16
+// (the arithmetic of lpc_negres16_dot2 in enc_common.h; qf in scalar registers).  The tap groups
+// nest: the first one the candidate's order does not reach ends the chain with one branch.
+template <int OFF, int JJ>
+__device__ __forceinline__ void sw_dot2_groups(const int32_t (&PW)[SW_W], const int32_t (&qf)[SW_NQF], uint32_t order, int32_t (&sum)[16])
+{
+	if constexpr (JJ < SW_NQF) {
+		if ((uint32_t)(2 * JJ) <= order) {
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				sum[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, PW[SW_HIST + OFF + i - 2 * JJ]), __builtin_bit_cast(fa_short2, qf[JJ]), sum[i], false);
+			sw_dot2_groups<OFF, JJ + 1>(PW, qf, order, sum);
+		}
+	}
+}
+
+template <int OFF>
+__device__ __forceinline__ void sw_negres_dot2(const int32_t (&PW)[SW_W], const int32_t (&qf)[SW_NQF], uint32_t order, uint32_t shift, uint32_t c31,
+                                               uint32_t (&x)[16])
+{
+	int32_t sum[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(sum[i]) : "v"(PW[SW_HIST + OFF + i]), "s"(qf[0]), "v"(c31));
+	sw_dot2_groups<OFF, 1>(PW, qf, order, sum);
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		x[i] = (uint32_t)sum[i] >> shift;
+}
+
+// the same with a tap per v_mad_i32_i24 (lpc_negres16_taps in enc_common.h)
+template <int OFF, int J>
+__device__ __forceinline__ void sw_taps_groups(const int32_t (&d)[SW_W], const int32_t (&q)[SW_HIST], uint32_t order, uint32_t (&sum)[16])
+{
+	if constexpr (J < SW_HIST) {
+		if ((uint32_t)J < order) {
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				sum[i] += (uint32_t)__mul24(q[J], d[SW_HIST + OFF + i - 1 - J]);
+			sw_taps_groups<OFF, J + 1>(d, q, order, sum);
+		}
+	}
+}
+
+template <int OFF>
+__device__ __forceinline__ void sw_negres_taps(const int32_t (&d)[SW_W], const int32_t (&q)[SW_HIST], uint32_t order, uint32_t shift, uint32_t c31,
+                                               uint32_t (&x)[16])
+{
+	uint32_t sum[16];
+	const int32_t m2s = -(int32_t)(1u << shift);
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		sum[i] = (uint32_t)__mul24(m2s, d[SW_HIST + OFF + i]) + c31;
+	sw_taps_groups<OFF, 0>(d, q, order, sum);
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		x[i] = sum[i] >> shift;
+}
+
+// the warm-up samples (the first `order` of the frame: lane 0, first block only) count as zero
+template <int I>
+__device__ __forceinline__ void sw_warm_up(uint32_t (&x)[16], uint32_t Bc, uint32_t order, bool lane0)
+{
+	if constexpr (I < SW_HIST) {
+		if ((uint32_t)I < order) {
+			x[I] = lane0 ? Bc : x[I];
+			sw_warm_up<I + 1>(x, Bc, order, lane0);
+		}
+	}
+}
+
+// |residual| of sixteen samples added to the lane's sum.  partial (the same in every lane): the frame is
+// the stream's short last one and only the first nv0 - OFF of these sixteen samples belong to it.
+template <int OFF>
+__device__ __forceinline__ uint32_t sw_add_abs(uint32_t (&x)[16], uint32_t Bc, uint32_t order, bool lane0, bool partial, uint32_t nv0, uint32_t t)
+{
+	if (OFF == 0)
+		sw_warm_up<0>(x, Bc, order, lane0);
+	if (partial) {
+		// (an opaque count: its sixteen comparisons are made here, not ahead of the candidate loop and kept)
+		uint32_t nv = nv0 > (uint32_t)OFF ? nv0 - (uint32_t)OFF : 0u;
+		asm volatile("" : "+v"(nv));
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			t = sad_u32((uint32_t)i < nv ? x[i] : Bc, Bc, t);
+		return t;
+	}
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+		t = sad_u32(x[i], Bc, t);
+	return t;
+}
+
+// The lane's sum for a candidate whose folded chain could leave 32 bits (fa_fold_exact fails: the
+// coefficients are too large for the shortcut, which does not happen with coefficients that come out
+// of a real signal).  Spelled out tap by tap in 64 bits from the samples in memory; wrap: the
+// candidate's sum is the reference's wrapping 32-bit one (lpc.c:265) rather than the 64-bit one
+// (lpc.c:531).  There for correctness, not speed.
+__device__ __forceinline__ uint32_t sw_lane_sum_exact(const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs, uint64_t frame_start,
+                                                   uint32_t s, uint32_t wasted, uint32_t ln, const int32_t *q, uint32_t order, int shift, bool wrap, uint32_t bsf)
+{
+	uint32_t t = 0;
+#pragma nounroll
+	for (uint32_t i = 0; i < SW_N; i++) {
+		const uint32_t idx = ln * SW_N + i;
+		if (idx < order || idx >= bsf)
+			continue;
+		int64_t sum = 0;
+#pragma nounroll
+		for (uint32_t j = 0; j < order; j++)
+			sum += (int64_t)q[j] * (int64_t)(fetch_signal(pcm, channels, sample_bytes, pairs, frame_start + idx - 1 - j, s) >> wasted);
+		const int32_t pred = wrap ? ((int32_t)sum >> shift) : (int32_t)(sum >> shift);
+		const int32_t d = fetch_signal(pcm, channels, sample_bytes, pairs, frame_start + idx, s) >> wasted;
+		t += abs32((int32_t)((uint32_t)d - (uint32_t)pred));
+	}
+	return t;
+}
+
+#define SW_DPP_ADD(x, ctrl) ((x) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, true))
+#define SW_DPP_PAIRS 0xB1   /* quad_perm [1,0,3,2] */
+#define SW_DPP_QUADS 0x4E   /* quad_perm [2,3,0,1] */
+#define SW_DPP_EIGHTS 0x141 /* row_half_mirror */
+#define SW_DPP_ROWS 0x140   /* row_mirror */
+
+// inclusive prefix sum over the wave's lanes: four shifts inside each row of sixteen, then the last
+// lane of row 0 (2) added to row 1 (3) and the last lane of row 1 to rows 2 and 3
+__device__ __forceinline__ uint32_t sw_scan_incl(uint32_t v)
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
+	return v;
+}
+
+// set_partitioned_rice_ (stream_encoder.c:3943) for every partition order of one candidate and the
+// scan of find_best_partition_order_ (stream_encoder.c:3700-3729), from the finest sums (lane l < 2^pm
+// holds sum l, truncated to 32 bits as the reference's accumulator is, stream_encoder.c:3803-3833).
+// Lane c prices finest partition c and "coarser item c": the partition whose level is the highest zero
+// bit of c below bit pm and whose index is the bits of c below that (every partition of every coarser
+// level is the item of exactly one lane, and those of one level sit in adjacent lanes).  A coarser
+// partition is a run of finest ones, so its sum is a difference of two prefix sums, fetched with two
+// lane permutes.  The bits of a level are then sums over aligned lane groups: four cross-lane adds and
+// a few scalar reads.  Out: the best order, its residual bits, and per lane the Rice parameters of its
+// two items (finest | coarser << 8).
+__device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn, uint32_t order, uint32_t seed, uint32_t bsf, uint32_t rice_limit,
+                                         uint32_t lane, uint32_t &bestb_out, uint32_t &bestpo_out, uint32_t &kpair_out)
+{
+	// (an opaque copy of the lane index: what is derived from it below is cheap, and computed afresh it
+	// does not sit in registers across the residual loops)
+	uint32_t ln = lane;
+	asm volatile("" : "+v"(ln));
+	const uint32_t full = (1u << pm) - 1u;
+	const bool mine = ln <= full;
+	const uint32_t zeros = ~ln & full;
+	const uint32_t poc = zeros ? ilog2u(zeros) : 0u;
+	const uint32_t pc = ln & ((1u << poc) - 1u);
+	const bool have_c = mine && zeros != 0 && poc >= pmn;
+	const uint32_t span = (pm - poc) & 31u;
+	const uint32_t first = pc << span, last = first + (1u << span) - 1u;   // the finest partitions the coarser item covers
+	const uint32_t nf = (bsf >> pm) - (ln == 0 ? order : 0u);
+	const uint32_t nc = (bsf >> poc) - (pc == 0 ? order : 0u);
+	// 32-bit arithmetic when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32)
+	const bool narrow = __all((fr >> 26) == 0);
+	uint32_t bf, bc, kf, kc;
+	if (narrow) {
+		const uint32_t incl = sw_scan_incl(fr);
+		const uint32_t excl = incl - fr;
+		const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)incl) - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first << 2), (int)excl);
+		kf = (pm == 0) ? seed : rice_k_from_sum32(fr, nf, rice_limit);
+		kc = (poc == 0) ? seed : rice_k_from_sum32(sc, nc, rice_limit);
+		bf = rice_bits_estimate32(kf, nf, fr);
+		bc = rice_bits_estimate32(kc, nc, sc);
+	} else {
+		const uint32_t tz = ln ? (uint32_t)__builtin_ctz(ln) : 0u;
+		const uint32_t src = (2u * pc + 1u) << ((pm - 1u - poc) & 31u);   // the lane that holds the item's sum after the exchanges
+		uint64_t v[7];
+		v[0] = fr;
+#pragma unroll
+		for (int j = 0; j < 6; j++)
+			v[j + 1] = v[j] + (uint64_t)__shfl_xor((unsigned long long)v[j], 1 << j, 64);
+		uint64_t up = v[1];
+#pragma unroll
+		for (int j = 1; j < 6; j++)
+			up = tz == (uint32_t)j ? v[j + 1] : up;
+		const uint64_t sc = (uint64_t)__shfl((unsigned long long)up, (int)src, 64);
+		kf = (pm == 0) ? seed : rice_k_from_sum(v[0], nf, rice_limit);
+		kc = (poc == 0) ? seed : rice_k_from_sum(sc, nc, rice_limit);
+		bf = rice_bits_estimate(kf, nf, v[0]);
+		bc = rice_bits_estimate(kc, nc, sc);
+	}
+	kpair_out = kf | (kc << 8);
+	// bits per level: the finest one is the sum over the wave, level po that of the 2^po lanes from lane 2^pm - 2^(po+1) on
+	uint32_t wf[5], wc[5];
+	wf[0] = mine ? bf : 0u;
+	wc[0] = have_c ? bc : 0u;
+	wf[1] = SW_DPP_ADD(wf[0], SW_DPP_PAIRS);
+	wc[1] = SW_DPP_ADD(wc[0], SW_DPP_PAIRS);
+	wf[2] = SW_DPP_ADD(wf[1], SW_DPP_QUADS);
+	wc[2] = SW_DPP_ADD(wc[1], SW_DPP_QUADS);
+	wf[3] = SW_DPP_ADD(wf[2], SW_DPP_EIGHTS);
+	wc[3] = SW_DPP_ADD(wc[2], SW_DPP_EIGHTS);
+	wf[4] = SW_DPP_ADD(wf[3], SW_DPP_ROWS);
+	wc[4] = SW_DPP_ADD(wc[3], SW_DPP_ROWS);
+	// find_best_partition_order_: from the largest order down, a smaller one must be strictly better
+	uint32_t bestb = 6u + __builtin_amdgcn_readlane(wf[4], 0) + __builtin_amdgcn_readlane(wf[4], 16) + __builtin_amdgcn_readlane(wf[4], 32) +
+	                 __builtin_amdgcn_readlane(wf[4], 48);
+	uint32_t bestpo = pm;
+#pragma unroll
+	for (int po = 5; po >= 0; po--) {
+		if ((uint32_t)po < pm && (uint32_t)po >= pmn) {
+			const uint32_t at = (1u << pm) - (2u << po);
+			const uint32_t lb = po == 5 ? __builtin_amdgcn_readlane(wc[4], 0) + __builtin_amdgcn_readlane(wc[4], 16)
+			                            : __builtin_amdgcn_readlane(wc[po], at);
+			if (6u + lb < bestb) {
+				bestb = 6u + lb;
+				bestpo = (uint32_t)po;
+			}
+		}
+	}
+	bestb_out = bestb;
+	bestpo_out = bestpo;
+}
+
+__device__ __forceinline__ int32_t sw_pack16(int32_t hi, int32_t lo) { return (int32_t)(((uint32_t)hi << 16) | ((uint32_t)lo & 0xffffu)); }
+
+// One candidate predictor, the same in every lane.
+struct SwCand {
+	uint32_t kind, order, seed, precision, shift, mode, hdr_bits, slot;
+	uint64_t sumq;   // an upper bound of the sum of the coefficients' magnitudes
+	int32_t q[SW_HIST];
+};
+
+#define SW_TAPS 0
+#define SW_DOT2 1
+#define SW_REDO 0xffu   // plan type left by the two-taps launch for the one-tap launch to pick up
+
+template <int RES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaLpcCand *__restrict__ cands,
+                   const int32_t *__restrict__ coefs, FaPlan *__restrict__ plans, unsigned long long sig_list, uint32_t nsel)
+{
+	__shared__ __attribute__((aligned(16))) int32_t stage[17 * SW_ROW];
+	// Workgroups go to the chip's eight dies in turn, each with an L2 of its own: the waves of one frame's
+	// signals, which read the same samples, are given indices that are equal modulo eight.
+	const uint32_t f = (blockIdx.x / (8 * nsel)) * 8 + (blockIdx.x & 7u);
+	if (f >= B.nframes)
+		return;
+	const uint32_t s = (uint32_t)(sig_list >> (4 * ((blockIdx.x % (8 * nsel)) >> 3))) & 15u;
+	const uint32_t task = f * P.nsignals + s;
+	const uint32_t ln = threadIdx.x;
+	FaPlan *pl = plans + task;
+	if (RES == SW_TAPS && pl->type != SW_REDO)
+		return;   // the two-taps launch has done this one
+	const uint32_t bsf = frame_len(B, SW_N * 64, f);
+	const bool partial = bsf != SW_N * 64;   // the stream's short last frame
+	const uint64_t frame_start = (uint64_t)f * (SW_N * 64);
+	const uint32_t ncoef_all = P.ncand * P.max_lpc_order;
+	const FaLpcCand *my_cands = cands + (size_t)task * P.ncand;
+	const int32_t *my_coefs = coefs + (size_t)task * ncoef_all;
+
+	const FaSubStat st = stats[task];
+	const uint32_t sbps = st.bps, wasted = st.wasted;
+	const uint32_t hdr = 8 + wasted;
+	// process_subframes_ (stream_encoder.c:2929-2936): a full block has twelve factors of two, a short
+	// one is coded with partition order 0; format.c:548 never lowers the limit here (64 > 12)
+	const uint32_t pm = partial ? 0u : umin32(P.max_po, 6u);
+	const uint32_t pmn = umin32(P.min_po, pm);
+
+	// evaluate_verbatim_subframe_ (stream_encoder.c:3641), evaluate_constant_subframe_ (stream_encoder.c:3470)
+	uint32_t best_bits = (P.disable_verbatim && bsf >= 4) ? 0xffffffffu : hdr + bsf * sbps;
+	uint32_t best_type = FA_SUB_VERBATIM, best_order = 0, best_prec = 0, best_po = 0, best_mode = 0, best_slot = 0, best_shift = 0, best_c = 0;
+	int32_t best_const = 0;
+	if (bsf >= 4 && st.is_constant) {
+		const uint32_t cb = hdr + sbps;
+		if (cb < best_bits) {
+			best_type = FA_SUB_CONSTANT;
+			best_bits = cb;
+			best_const = st.first_sample;
+		}
+	}
+	uint32_t best_k = 0;   // per lane: Rice parameters of the best candidate's two items
+
+	if (bsf >= 4 && !st.is_constant) {
+		// ---- the lane's run of the signal: a quarter of the frame at a time goes through LDS, read with
+		// lanes along consecutive samples, stored as rows of 64, and sixteen lanes pick up a row each
+		// plus the tail of the row before it ----
+		int32_t d[SW_W];
+		{
+			const SigAccess a = sig_access(P.channels, B.sample_bytes, B.pairs, s);
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				uint32_t rel[17];
+				int32_t v[17];
+#pragma unroll
+				for (int i = 0; i < 17; i++) {
+					const int32_t idx = 1024 * p - 64 + 64 * i + (int32_t)ln;
+					rel[i] = idx < 0 ? 0u : umin32((uint32_t)idx, bsf - 1);
+				}
+				load_signal_block<17>(v, pcm, a, frame_start, rel);
+#pragma unroll
+				for (int i = 0; i < 17; i++) {
+					const int32_t idx = 1024 * p - 64 + 64 * i + (int32_t)ln;
+					stage[i * SW_ROW + ln] = (idx < 0 || (uint32_t)idx >= bsf) ? 0 : (v[i] >> wasted);
+				}
+				__syncthreads();
+				if ((ln >> 4) == (uint32_t)p) {
+					const int32_t *row = stage + ((ln & 15u) + 1u) * SW_ROW;
+#pragma unroll
+					for (int k = 0; k < SW_HIST; k++)
+						d[k] = row[-SW_ROW + 64 - SW_HIST + k];
+#pragma unroll
+					for (int k = 0; k < SW_N; k++)
+						d[SW_HIST + k] = row[k];
+				}
+				__syncthreads();
+			}
+		}
+		// Which arithmetic the residuals take is decided by what the samples are, not by what they could
+		// be: two taps per v_dot2_i32_i16 when every sample of the frame's signal fits 16 bits (always so
+		// for streams of up to 16 bits, nearly always so for their side signal), a tap per v_mad_i32_i24
+		// otherwise.  Both are exact, so the choice does not show in the result.  Each form is a launch of
+		// its own (the registers of one do not weigh on the other): the two-taps launch comes first and
+		// leaves the subframes it cannot take to the second, which looks at nothing else.
+		int32_t w[SW_W];
+		if (RES == SW_DOT2) {
+			uint32_t mag = 0;
+#pragma unroll
+			for (int k = 0; k < SW_W; k++)
+				mag |= (uint32_t)(d[k] ^ (d[k] >> 31));
+			if (wave_or(mag) >= 0x8000u) {
+				if (ln == 0)
+					pl->type = SW_REDO;
+				return;
+			}
+			// w[k] holds samples k - 1 and k of the window in its low and high half
+			w[0] = (int32_t)((uint32_t)d[0] << 16);
+#pragma unroll
+			for (int k = 1; k < SW_W; k++)
+				w[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k], (uint32_t)d[k - 1], 0x05040100u);
+		} else {
+#pragma unroll
+			for (int k = 0; k < SW_W; k++)
+				w[k] = d[k];
+		}
+		const uint32_t fold_bps = RES == SW_DOT2 ? umin32(sbps, 16u) : sbps;
+		const uint32_t c31 = 0x80000000u;
+		const bool lane0 = ln == 0;
+		const uint32_t nv0 = bsf > ln * SW_N ? bsf - ln * SW_N : 0u;   // samples of the lane's run inside the frame
+		const uint32_t total_cands = 5 + P.ncand;
+		const uint32_t rice_limit = P.rice_limit, max_lpc_order = P.max_lpc_order;
+
+		// The fixed predictors that take part (stream_encoder.c:3236-3287), six bits each: taking part, and the
+		// Rice parameter their residual starts from.
+		uint32_t fx = 0;
+		{
+			uint32_t lo, hi;
+			if (P.exhaustive) { lo = 0; hi = 4; }
+			else lo = hi = st.fixed_guess;
+			if (hi >= bsf) hi = bsf - 1;
+			const bool enabled = !P.disable_fixed || (P.max_lpc_order == 0 && best_bits == 0xffffffffu);
+#pragma unroll
+			for (uint32_t o = 0; o < 5; o++) {
+				const float rb = st.rbps[o];
+				if (enabled && o >= lo && o <= hi && !(rb >= (float)sbps)) {
+					uint32_t rice = (rb > 0.0f) ? (uint32_t)((double)rb + 0.5) : 0u;
+					rice++;
+					if (rice >= rice_limit) rice = rice_limit - 1;
+					fx |= (32u | rice) << (6 * o);
+				}
+			}
+			fx = __builtin_amdgcn_readfirstlane(fx);
+		}
+
+		// candidate c of the reference's trial order: fixed orders ascending, then the LPC candidates as
+		// k_lpc listed them.  False: it does not take part.
+		auto candidate = [&](uint32_t c, SwCand &k) -> bool {
+#pragma unroll
+			for (int j = 0; j < SW_HIST; j++)
+				k.q[j] = 0;
+			if (c < 5) {
+				// a fixed predictor of order o is the filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 (fixed.c:352-388)
+				const uint32_t e = (fx >> (6 * c)) & 63u;
+				if (!(e & 32u))
+					return false;
+				const uint32_t order = c;
+				k.kind = FA_SUB_FIXED;
+				k.order = order;
+				k.seed = e & 31u;
+				k.precision = 0;
+				k.shift = 0;
+				k.slot = 0;
+				k.hdr_bits = hdr + order * sbps;
+				k.sumq = (1u << order) - 1u;
+				k.mode = (uint32_t)lpc_mode(0, sbps);
+				k.q[0] = (int32_t)order;
+				k.q[1] = order == 2 ? -1 : order == 3 ? -3 : order == 4 ? -6 : 0;
+				k.q[2] = order == 3 ? 1 : order == 4 ? 4 : 0;
+				k.q[3] = order == 4 ? -1 : 0;
+				return true;
+			}
+			const uint32_t slot = c - 5;
+			// (the slot is the same in every lane: its words and the coefficients below belong in scalar registers)
+			const uint2 lcw = *(const uint2 *)(my_cands + slot);
+			const uint32_t w0 = __builtin_amdgcn_readfirstlane(lcw.x), w1 = __builtin_amdgcn_readfirstlane(lcw.y);
+			if (!(w0 & 0xffu))   // FaLpcCand: valid, order, precision, shift | rice, wide, sumq32
+				return false;
+			const uint32_t order = (w0 >> 8) & 0xffu;
+			k.kind = FA_SUB_LPC;
+			k.order = order;
+			k.precision = (w0 >> 16) & 0xffu;
+			k.shift = (uint32_t)(int32_t)(int8_t)(w0 >> 24);
+			k.seed = w1 & 0xffu;
+			k.mode = (uint32_t)lpc_mode((w1 >> 8) & 0xffu, sbps);
+			k.slot = slot;
+			k.hdr_bits = hdr + 4 + 5 + order * (k.precision + sbps);
+			k.sumq = (uint64_t)(w1 >> 16) << 5;
+			const int32_t *cq = my_coefs + slot * max_lpc_order;
+#pragma unroll
+			for (int j = 0; j < SW_HIST; j++) {
+				const int32_t qj = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)cq[j]);   // the buffer ends in slack, so the twelve reads are always inside it
+				k.q[j] = (uint32_t)j < order ? qj : 0;
+			}
+			return true;
+		};
+		// price candidate c from its lanes' sums and keep it if it beats what came before: in trial order a
+		// later one must be strictly better (stream_encoder.c:3283,3372); `late` candidates are looked at after
+		// the others and win ties against those that follow them in trial order
+		auto consider = [&](uint32_t c, const SwCand &k, uint32_t t, bool late) {
+			// the finest partitions of the frame cover 2^(6 - pm) lanes each; lane p takes the sum of partition p
+			// (modulo 2^32, which is the reference's accumulator at these sizes, stream_encoder.c:3803)
+			uint32_t fr = t;
+			if (pm < 6) {
+#pragma unroll
+				for (int j = 0; j < 6; j++)
+					if ((uint32_t)j < 6 - pm)
+						fr += (uint32_t)__shfl_xor((int)fr, 1 << j, 64);
+				fr = (uint32_t)__shfl((int)fr, (int)((ln << (6 - pm)) & 63u), 64);
+				if (ln >= (1u << pm))
+					fr = 0;
+			}
+			uint32_t bestb, bestpo, kpair;
+			sw_price(fr, pm, pmn, k.order, k.seed, bsf, rice_limit, ln, bestb, bestpo, kpair);
+			const uint32_t total = k.hdr_bits + bestb;
+			if (total < best_bits || (late && total == best_bits && c < best_c)) {
+				best_bits = total;
+				best_type = k.kind;
+				best_order = k.order;
+				best_prec = k.precision;
+				best_shift = k.shift;
+				best_po = bestpo;
+				best_mode = k.mode;
+				best_slot = k.slot;
+				best_c = c;
+				best_k = kpair;
+			}
+		};
+
+		bool any_late = false;
+#pragma nounroll
+		for (uint32_t c = 0; c < total_cands; c++) {
+			SwCand k;
+			if (!candidate(c, k))
+				continue;
+			if (!fa_fold_exact(k.sumq, k.shift, fold_bps)) {
+				any_late = true;   // the folded chain could leave 32 bits: done exactly, below
+				continue;
+			}
+			const uint32_t order = k.order, shift = k.shift;
+			const uint32_t Bc = c31 >> shift;
+			uint32_t t = 0;
+			uint32_t x[16];
+			if (RES == SW_DOT2) {
+				// c[0] = -2^shift, c[m] = q[m - 1], two to a word
+				int32_t qf[SW_NQF];
+				qf[0] = sw_pack16(-(int32_t)(1u << shift), k.q[0]);
+#pragma unroll
+				for (int jj = 1; jj < SW_NQF; jj++)
+					qf[jj] = sw_pack16(k.q[2 * jj - 1], 2 * jj < SW_HIST ? k.q[2 * jj] : 0);
+				sw_negres_dot2<0>(w, qf, order, shift, c31, x);
+				t = sw_add_abs<0>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_dot2<16>(w, qf, order, shift, c31, x);
+				t = sw_add_abs<16>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_dot2<32>(w, qf, order, shift, c31, x);
+				t = sw_add_abs<32>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_dot2<48>(w, qf, order, shift, c31, x);
+				t = sw_add_abs<48>(x, Bc, order, lane0, partial, nv0, t);
+			} else {
+				sw_negres_taps<0>(w, k.q, order, shift, c31, x);
+				t = sw_add_abs<0>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_taps<16>(w, k.q, order, shift, c31, x);
+				t = sw_add_abs<16>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_taps<32>(w, k.q, order, shift, c31, x);
+				t = sw_add_abs<32>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_taps<48>(w, k.q, order, shift, c31, x);
+				t = sw_add_abs<48>(x, Bc, order, lane0, partial, nv0, t);
+			}
+			consider(c, k, t, false);
+		}
+		if (any_late) {
+#pragma nounroll
+			for (uint32_t c = 0; c < total_cands; c++) {
+				SwCand k;
+				if (!candidate(c, k) || fa_fold_exact(k.sumq, k.shift, fold_bps))
+					continue;
+				const uint32_t t = sw_lane_sum_exact(pcm, P.channels, B.sample_bytes, B.pairs, frame_start, s, wasted, ln, k.q, k.order, (int)k.shift, k.mode != 2u, bsf);
+				consider(c, k, t, true);
+			}
+		}
+	}
+	if (best_bits == 0xffffffffu) {
+		// stream_encoder.c:3388-3391
+		best_type = FA_SUB_VERBATIM;
+		best_bits = hdr + bsf * sbps;
+	}
+	// ---- the plan ----
+	uint32_t rice2 = 0;
+	if (best_type == FA_SUB_FIXED || best_type == FA_SUB_LPC) {
+		// the winner's parameters at its partition order: the finest items when that is the largest order, else
+		// the coarser items of the lanes from 2^pm - 2^(po+1) on
+		const uint32_t from = best_po == pm ? ln : ((1u << pm) - (2u << best_po) + ln) & 63u;
+		const uint32_t kk = (uint32_t)__shfl((int)best_k, (int)from, 64);
+		const uint32_t k = best_po == pm ? (kk & 0xffu) : (kk >> 8);
+		const bool have = ln < (1u << best_po);
+		if (have)
+			pl->params[ln] = (uint8_t)k;
+		rice2 = __ballot(have && k >= 15) ? 1u : 0u;   // stream_encoder.c:3752-3757
+		if (best_type == FA_SUB_LPC && ln < best_order)
+			pl->q[ln] = my_coefs[best_slot * P.max_lpc_order + ln];
+	}
+	if (ln == 0) {
+		pl->bits = best_bits;
+		pl->type = (uint8_t)best_type;
+		pl->order = (uint8_t)best_order;
+		pl->precision = (uint8_t)best_prec;
+		pl->shift = (int8_t)best_shift;
+		pl->part_order = (uint8_t)best_po;
+		pl->rice2 = (uint8_t)rice2;
+		pl->wide = (uint8_t)best_mode;
+		pl->pad = 0;
+		pl->constant = best_const;
+	}
+}
+
+// Whether the wave form can take this stream's frames (the launcher still chooses the signals).
+bool fa_search_wave_eligible(const FaEncParams &P)
+{
+	if (P.blocksize != SW_N * 64 || P.max_po > 6 || P.max_lpc_order > SW_HIST)
+		return false;
+	// the reference's 32-bit partition sums (stream_encoder.c:3803) at every partition order this block can use
+	return 12 + P.bps + (P.do_ms ? 1u : 0u) < 32;
+}
+
+// wide_list: those of the signals that can be wider than 16 bits (the rest never need the second launch)
+void fa_launch_search_wave(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
+                           const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, unsigned long long wide_list, uint32_t nwide,
+                           hipStream_t st)
+{
+	const dim3 block(64);
+	hipLaunchKernelGGL(k_search_wave<SW_DOT2>, dim3((B.nframes + 7) / 8 * 8 * nsel), block, 0, st, P, B, pcm, stats, cands, coefs, plans, sig_list, nsel);
+	if (nwide)
+		hipLaunchKernelGGL(k_search_wave<SW_TAPS>, dim3((B.nframes + 7) / 8 * 8 * nwide), block, 0, st, P, B, pcm, stats, cands, coefs, plans, wide_list, nwide);
+}
