@@ -1,8 +1,8 @@
 // FLAC frame encoder kernels for gfx950 (MI355X): the model search with a wave per subframe.
 #include <hip/hip_runtime.h>
 
-#include "enc_common.h"
 #include "enc_kernels.h"
+#include "enc_wave.h"
 
 // ---------------------------------------------------------------------------------------------
 // k_search_wave: process_subframe_ (stream_encoder.c:3164) for one (frame, signal) of a stream with
@@ -18,12 +18,6 @@
 // live in scalar registers, loaded with scalar loads.  Four such waves share a SIMD and fill each
 // other's stalls; nothing in the kernel is a barrier between waves.
 // ---------------------------------------------------------------------------------------------
-#define SW_N 64                  // samples per lane
-#define SW_HIST 12               // history in front of them = largest predictor order
-#define SW_W (SW_HIST + SW_N)
-#define SW_ROW 68                // LDS words per staged row of 64 samples (four words of padding)
-#define SW_NQF (SW_HIST / 2 + 1) // words of the folded two-taps form (see lpc_negres16_dot2)
-
 // Sixteen samples' sums are finished (shifted, added up) before the next sixteen start: the optimiser,
 // left alone, sinks every shift and add to the end of the candidate, keeps all 64 chains alive until
 // then and runs out of registers.  An empty volatile statement that "uses" the running sum pins them.
@@ -55,38 +49,15 @@ __device__ __forceinline__ void sw_negres_dot2(const int32_t (&PW)[SW_W], const 
 	for (int i = 0; i < 16; i++)
 		asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(sum[i]) : "v"(PW[SW_HIST + OFF + i]), "s"(qf[0]), "v"(c31));
 	sw_dot2_groups<OFF, 1>(PW, qf, order, sum);
+	if (shift) {
 #pragma unroll
-	for (int i = 0; i < 16; i++)
-		x[i] = (uint32_t)sum[i] >> shift;
-}
-
-// the same with a tap per v_mad_i32_i24 (lpc_negres16_taps in enc_common.h)
-template <int OFF, int J>
-__device__ __forceinline__ void sw_taps_groups(const int32_t (&d)[SW_W], const int32_t (&q)[SW_HIST], uint32_t order, uint32_t (&sum)[16])
-{
-	if constexpr (J < SW_HIST) {
-		if ((uint32_t)J < order) {
+		for (int i = 0; i < 16; i++)
+			x[i] = (uint32_t)sum[i] >> shift;
+	} else {   // the fixed predictors
 #pragma unroll
-			for (int i = 0; i < 16; i++)
-				sum[i] += (uint32_t)__mul24(q[J], d[SW_HIST + OFF + i - 1 - J]);
-			sw_taps_groups<OFF, J + 1>(d, q, order, sum);
-		}
+		for (int i = 0; i < 16; i++)
+			x[i] = (uint32_t)sum[i];
 	}
-}
-
-template <int OFF>
-__device__ __forceinline__ void sw_negres_taps(const int32_t (&d)[SW_W], const int32_t (&q)[SW_HIST], uint32_t order, uint32_t shift, uint32_t c31,
-                                               uint32_t (&x)[16])
-{
-	uint32_t sum[16];
-	const int32_t m2s = -(int32_t)(1u << shift);
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-		sum[i] = (uint32_t)__mul24(m2s, d[SW_HIST + OFF + i]) + c31;
-	sw_taps_groups<OFF, 0>(d, q, order, sum);
-#pragma unroll
-	for (int i = 0; i < 16; i++)
-		x[i] = sum[i] >> shift;
 }
 
 // the warm-up samples (the first `order` of the frame: lane 0, first block only) count as zero
@@ -148,6 +119,23 @@ __device__ __forceinline__ uint32_t sw_lane_sum_exact(const void *pcm, uint32_t 
 	return t;
 }
 
+// rice_k_from_sum32 / rice_bits_estimate32 (enc_common.h; stream_encoder.c:4047-4054, 3918) as straight-line
+// code: selects instead of branches on per-lane conditions, 24-bit multiplies (n <= 4096, k < 32)
+__device__ __forceinline__ uint32_t sw_rice_k32(uint32_t sum, uint32_t n, uint32_t limit)
+{
+	const uint32_t cs = umin32((uint32_t)__clz((int)sum), 32u), cn = (uint32_t)__clz((int)n);   // n >= 1
+	uint32_t k = cn > cs ? cn - cs : 0u;       // ilog2(sum) - ilog2(n) when sum > n
+	k += ((n << k) < sum) ? 1u : 0u;
+	k = sum > n ? k : 0u;
+	return umin32(k, limit - 1u);
+}
+
+__device__ __forceinline__ uint32_t sw_rice_bits32(uint32_t k, uint32_t n, uint32_t sum)
+{
+	const uint32_t tail = k ? (sum >> ((k - 1u) & 31u)) : (sum << 1);
+	return 4u + __umul24(1u + k, n) + tail - (n >> 1);
+}
+
 #define SW_DPP_ADD(x, ctrl) ((x) + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, 0xf, 0xf, true))
 #define SW_DPP_PAIRS 0xB1   /* quad_perm [1,0,3,2] */
 #define SW_DPP_QUADS 0x4E   /* quad_perm [2,3,0,1] */
@@ -177,36 +165,54 @@ __device__ __forceinline__ uint32_t sw_scan_incl(uint32_t v)
 // lane permutes.  The bits of a level are then sums over aligned lane groups: four cross-lane adds and
 // a few scalar reads.  Out: the best order, its residual bits, and per lane the Rice parameters of its
 // two items (finest | coarser << 8).
-__device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn, uint32_t order, uint32_t seed, uint32_t bsf, uint32_t rice_limit,
-                                         uint32_t lane, uint32_t &bestb_out, uint32_t &bestpo_out, uint32_t &kpair_out)
+// What a lane's two items are does not depend on the candidate: SwLane holds it, worked out once per wave.
+struct SwLane {
+	uint32_t packed;             // first << 2 | last << 10 | poc << 18: the finest partitions [first, last] the coarser item covers, and its level
+	bool mine, have_c, lane0, pc0;   // lane prices a finest partition / a coarser one; the items that start the frame (they hold the warm-up samples)
+};
+
+__device__ __forceinline__ SwLane sw_lane_items(uint32_t ln, uint32_t pm, uint32_t pmn)
 {
-	// (an opaque copy of the lane index: what is derived from it below is cheap, and computed afresh it
-	// does not sit in registers across the residual loops)
-	uint32_t ln = lane;
-	asm volatile("" : "+v"(ln));
+	SwLane L;
 	const uint32_t full = (1u << pm) - 1u;
-	const bool mine = ln <= full;
 	const uint32_t zeros = ~ln & full;
 	const uint32_t poc = zeros ? ilog2u(zeros) : 0u;
 	const uint32_t pc = ln & ((1u << poc) - 1u);
-	const bool have_c = mine && zeros != 0 && poc >= pmn;
 	const uint32_t span = (pm - poc) & 31u;
-	const uint32_t first = pc << span, last = first + (1u << span) - 1u;   // the finest partitions the coarser item covers
-	const uint32_t nf = (bsf >> pm) - (ln == 0 ? order : 0u);
-	const uint32_t nc = (bsf >> poc) - (pc == 0 ? order : 0u);
+	const uint32_t first = (pc << span) & 63u, last = (first + (1u << span) - 1u) & 63u;
+	L.packed = (first << 2) | (last << 10) | (poc << 18);
+	L.mine = ln <= full;
+	L.have_c = L.mine && zeros != 0 && poc >= pmn;
+	L.lane0 = ln == 0;
+	L.pc0 = pc == 0;
+	return L;
+}
+
+__device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn, uint32_t order, uint32_t seed, uint32_t bsf, uint32_t rice_limit,
+                                         uint32_t lane, const SwLane &L, uint32_t &bestb_out, uint32_t &bestpo_out, uint32_t &kpair_out)
+{
+	const bool mine = L.mine, have_c = L.have_c;
+	const uint32_t poc = (L.packed >> 18) & 7u;
+	const uint32_t nf = (bsf >> pm) - (L.lane0 ? order : 0u);
+	const uint32_t nc = (bsf >> poc) - (L.pc0 ? order : 0u);
 	// 32-bit arithmetic when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32)
 	const bool narrow = __all((fr >> 26) == 0);
 	uint32_t bf, bc, kf, kc;
 	if (narrow) {
 		const uint32_t incl = sw_scan_incl(fr);
 		const uint32_t excl = incl - fr;
-		const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(last << 2), (int)incl) - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(first << 2), (int)excl);
-		kf = (pm == 0) ? seed : rice_k_from_sum32(fr, nf, rice_limit);
-		kc = (poc == 0) ? seed : rice_k_from_sum32(sc, nc, rice_limit);
-		bf = rice_bits_estimate32(kf, nf, fr);
-		bc = rice_bits_estimate32(kc, nc, sc);
+		const uint32_t sc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((L.packed >> 8) & 0xfcu), (int)incl) -
+		                    (uint32_t)__builtin_amdgcn_ds_bpermute((int)(L.packed & 0xfcu), (int)excl);
+		kf = (pm == 0) ? seed : sw_rice_k32(fr, nf, rice_limit);
+		kc = (poc == 0) ? seed : sw_rice_k32(sc, nc, rice_limit);
+		bf = sw_rice_bits32(kf, nf, fr);
+		bc = sw_rice_bits32(kc, nc, sc);
 	} else {
+		// (sums that need 64 bits: pathological input; the exchange pattern of the workgroup form)
+		uint32_t ln = lane;
+		asm volatile("" : "+v"(ln));
 		const uint32_t tz = ln ? (uint32_t)__builtin_ctz(ln) : 0u;
+		const uint32_t pc = ln & ((1u << poc) - 1u);
 		const uint32_t src = (2u * pc + 1u) << ((pm - 1u - poc) & 31u);   // the lane that holds the item's sum after the exchanges
 		uint64_t v[7];
 		v[0] = fr;
@@ -320,36 +326,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		// lanes along consecutive samples, stored as rows of 64, and sixteen lanes pick up a row each
 		// plus the tail of the row before it ----
 		int32_t d[SW_W];
-		{
-			const SigAccess a = sig_access(P.channels, B.sample_bytes, B.pairs, s);
-#pragma unroll
-			for (int p = 0; p < 4; p++) {
-				uint32_t rel[17];
-				int32_t v[17];
-#pragma unroll
-				for (int i = 0; i < 17; i++) {
-					const int32_t idx = 1024 * p - 64 + 64 * i + (int32_t)ln;
-					rel[i] = idx < 0 ? 0u : umin32((uint32_t)idx, bsf - 1);
-				}
-				load_signal_block<17>(v, pcm, a, frame_start, rel);
-#pragma unroll
-				for (int i = 0; i < 17; i++) {
-					const int32_t idx = 1024 * p - 64 + 64 * i + (int32_t)ln;
-					stage[i * SW_ROW + ln] = (idx < 0 || (uint32_t)idx >= bsf) ? 0 : (v[i] >> wasted);
-				}
-				__syncthreads();
-				if ((ln >> 4) == (uint32_t)p) {
-					const int32_t *row = stage + ((ln & 15u) + 1u) * SW_ROW;
-#pragma unroll
-					for (int k = 0; k < SW_HIST; k++)
-						d[k] = row[-SW_ROW + 64 - SW_HIST + k];
-#pragma unroll
-					for (int k = 0; k < SW_N; k++)
-						d[SW_HIST + k] = row[k];
-				}
-				__syncthreads();
-			}
-		}
+		sw_load_run(d, stage, pcm, sig_access(P.channels, B.sample_bytes, B.pairs, s), frame_start, bsf, partial, wasted, ln);
 		// Which arithmetic the residuals take is decided by what the samples are, not by what they could
 		// be: two taps per v_dot2_i32_i16 when every sample of the frame's signal fits 16 bits (always so
 		// for streams of up to 16 bits, nearly always so for their side signal), a tap per v_mad_i32_i24
@@ -358,14 +335,16 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		// leaves the subframes it cannot take to the second, which looks at nothing else.
 		int32_t w[SW_W];
 		if (RES == SW_DOT2) {
-			uint32_t mag = 0;
+			if (P.bps + ((P.do_ms && s == P.channels + 1) ? 1u : 0u) > 16) {
+				uint32_t mag = 0;
 #pragma unroll
-			for (int k = 0; k < SW_W; k++)
-				mag |= (uint32_t)(d[k] ^ (d[k] >> 31));
-			if (wave_or(mag) >= 0x8000u) {
-				if (ln == 0)
-					pl->type = SW_REDO;
-				return;
+				for (int k = 0; k < SW_W; k++)
+					mag |= (uint32_t)(d[k] ^ (d[k] >> 31));
+				if (wave_or(mag) >= 0x8000u) {
+					if (ln == 0)
+						pl->type = SW_REDO;
+					return;
+				}
 			}
 			// w[k] holds samples k - 1 and k of the window in its low and high half
 			w[0] = (int32_t)((uint32_t)d[0] << 16);
@@ -383,6 +362,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		const uint32_t nv0 = bsf > ln * SW_N ? bsf - ln * SW_N : 0u;   // samples of the lane's run inside the frame
 		const uint32_t total_cands = 5 + P.ncand;
 		const uint32_t rice_limit = P.rice_limit, max_lpc_order = P.max_lpc_order;
+		const SwLane items = sw_lane_items(ln, pm, pmn);
 
 		// The fixed predictors that take part (stream_encoder.c:3236-3287), six bits each: taking part, and the
 		// Rice parameter their residual starts from.
@@ -474,7 +454,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 					fr = 0;
 			}
 			uint32_t bestb, bestpo, kpair;
-			sw_price(fr, pm, pmn, k.order, k.seed, bsf, rice_limit, ln, bestb, bestpo, kpair);
+			sw_price(fr, pm, pmn, k.order, k.seed, bsf, rice_limit, ln, items, bestb, bestpo, kpair);
 			const uint32_t total = k.hdr_bits + bestb;
 			if (total < best_bits || (late && total == best_bits && c < best_c)) {
 				best_bits = total;
