@@ -142,19 +142,6 @@ __device__ __forceinline__ uint32_t sw_rice_bits32(uint32_t k, uint32_t n, uint3
 #define SW_DPP_EIGHTS 0x141 /* row_half_mirror */
 #define SW_DPP_ROWS 0x140   /* row_mirror */
 
-// inclusive prefix sum over the wave's lanes: four shifts inside each row of sixteen, then the last
-// lane of row 0 (2) added to row 1 (3) and the last lane of row 1 to rows 2 and 3
-__device__ __forceinline__ uint32_t sw_scan_incl(uint32_t v)
-{
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
-	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
-	return v;
-}
-
 // set_partitioned_rice_ (stream_encoder.c:3943) for every partition order of one candidate and the
 // scan of find_best_partition_order_ (stream_encoder.c:3700-3729), from the finest sums (lane l < 2^pm
 // holds sum l, truncated to 32 bits as the reference's accumulator is, stream_encoder.c:3803-3833).

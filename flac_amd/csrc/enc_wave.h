@@ -97,4 +97,17 @@ __device__ __forceinline__ void sw_negres_taps(const int32_t (&d)[SW_W], const i
 	}
 }
 
+// inclusive prefix sum over the wave's lanes: four shifts inside each row of sixteen, then the last
+// lane of row 0 (2) added to row 1 (3) and the last lane of row 1 to rows 2 and 3
+__device__ __forceinline__ uint32_t sw_scan_incl(uint32_t v)
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
+	return v;
+}
+
 #endif

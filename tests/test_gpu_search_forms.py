@@ -1,5 +1,5 @@
 """The model search has two forms on the device: a workgroup per subframe (any block size, any
-sample width) and a wave per subframe (full blocks of 4096 samples of streams up to 16 bits, the
+sample width) and a wave per subframe (blocks of 4096 samples of streams up to 16 bits, the
 benchmark's shape).  Both restate process_subframe_ (stream_encoder.c:3164) and must choose the same
 model for every subframe, so the frames they lead to must be the same bytes.  The golden cases pin the
 workgroup form (and, where their block size is 4096, the wave form) to the reference's bytes; this test
