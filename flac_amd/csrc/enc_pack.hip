@@ -1,8 +1,12 @@
 // FLAC frame encoder kernels for gfx950 (MI355X), part 3: bit packing of the chosen subframes.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "enc_common.h"
 #include "enc_kernels.h"
+#include "enc_wave.h"
 
 // ---------------------------------------------------------------------------------------------
 // k_pack
@@ -11,11 +15,11 @@
 
 __constant__ uint16_t c_crc16_table[256];
 __constant__ uint16_t c_crc16_pow[32];  // x^(8 * 2^j) mod the CRC-16 polynomial
-__constant__ uint8_t c_crc8_table[256];
+__constant__ uint8_t c_crc8_table[256] __attribute__((aligned(16)));
 __constant__ uint16_t c_crc16x4[4][256];    // table k: CRC-16 of a byte followed by k zero bytes
 // window_crc16 works on 256 runs of 1 << c words; thread t's run is followed by 255 - t more
 // runs, so its CRC is multiplied by c_crc16_runpow[c][t] = x^(8 * 4 * (1 << c) * (255 - t))
-#define PK_RUN_CLASSES 5
+#define PK_RUN_CLASSES 6
 __constant__ uint16_t c_crc16_runpow[PK_RUN_CLASSES][FA_THREADS];
 
 hipError_t fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8)
@@ -92,6 +96,106 @@ __device__ __forceinline__ uint32_t gf16_xpow8(uint32_t n)
 	return r;
 }
 
+// The bytes of a frame header (at most 16) are collected in two 64-bit words, first byte on top.
+__device__ __forceinline__ void hdr_put(uint64_t (&hw)[2], uint32_t &n, uint32_t byte)
+{
+	const uint64_t v = (uint64_t)(byte & 0xff) << (56 - 8 * (n & 7));
+	if (n < 8)
+		hw[0] |= v;
+	else
+		hw[1] |= v;
+	n++;
+}
+
+__device__ __forceinline__ uint32_t hdr_get(const uint64_t (&hw)[2], uint32_t i) { return (uint32_t)((i < 8 ? hw[0] : hw[1]) >> (56 - 8 * (i & 7))) & 0xff; }
+
+// FLAC__frame_add_header (stream_encoder_framing.c:219) up to, not including, its CRC-8; returns the
+// number of bytes.  Every argument is the same in all threads.
+__device__ __forceinline__ uint32_t frame_header_bytes(const FaEncParams &P, uint32_t bsf, uint32_t frame_number, uint32_t ca, uint64_t (&hw)[2])
+{
+	hw[0] = hw[1] = 0;
+	uint32_t n = 0;
+	auto put = [&](uint32_t byte) { hdr_put(hw, n, byte); };
+	put(0xff);
+	put(0xf8);
+	uint32_t u, bs_hint = 0, sr_hint = 0;
+	switch (bsf) {
+	case 192: u = 1; break;
+	case 576: u = 2; break;
+	case 1152: u = 3; break;
+	case 2304: u = 4; break;
+	case 4608: u = 5; break;
+	case 256: u = 8; break;
+	case 512: u = 9; break;
+	case 1024: u = 10; break;
+	case 2048: u = 11; break;
+	case 4096: u = 12; break;
+	case 8192: u = 13; break;
+	case 16384: u = 14; break;
+	case 32768: u = 15; break;
+	default: bs_hint = u = bsf <= 0x100 ? 6 : 7; break;
+	}
+	uint32_t v;
+	switch (P.sample_rate) {
+	case 88200: v = 1; break;
+	case 176400: v = 2; break;
+	case 192000: v = 3; break;
+	case 8000: v = 4; break;
+	case 16000: v = 5; break;
+	case 22050: v = 6; break;
+	case 24000: v = 7; break;
+	case 32000: v = 8; break;
+	case 44100: v = 9; break;
+	case 48000: v = 10; break;
+	case 96000: v = 11; break;
+	default:
+		if (P.sample_rate <= 255000 && P.sample_rate % 1000 == 0) sr_hint = v = 12;
+		else if (P.sample_rate % 10 == 0) sr_hint = v = 14;
+		else if (P.sample_rate <= 0xffff) sr_hint = v = 13;
+		else v = 0;
+		break;
+	}
+	put((uint8_t)((u << 4) | v));
+	const uint32_t chcode = ca == 0 ? P.channels - 1 : 7 + ca;
+	uint32_t bcode;
+	switch (P.bps) {
+	case 8: bcode = 1; break;
+	case 12: bcode = 2; break;
+	case 16: bcode = 4; break;
+	case 20: bcode = 5; break;
+	case 24: bcode = 6; break;
+	default: bcode = 0; break;
+	}
+	put((uint8_t)((chcode << 4) | (bcode << 1)));
+	// FLAC__bitwriter_write_utf8_uint32 (bitwriter.c:784)
+	const uint32_t val = frame_number;
+	if (val < 0x80)
+		put((uint8_t)val);
+	else {
+		const int cont = val < 0x800 ? 1 : val < 0x10000 ? 2 : val < 0x200000 ? 3 : val < 0x4000000 ? 4 : 5;
+		const uint32_t lead = (0xff00u >> (cont + 1)) & 0xff;  // 0xC0, 0xE0, 0xF0, 0xF8, 0xFC
+		put((uint8_t)(lead | (val >> (6 * cont))));
+		for (int i = cont - 1; i >= 0; i--)
+			put((uint8_t)(0x80 | ((val >> (6 * i)) & 0x3f)));
+	}
+	if (bs_hint == 6)
+		put((uint8_t)(bsf - 1));
+	else if (bs_hint == 7) {
+		put((uint8_t)((bsf - 1) >> 8));
+		put((uint8_t)(bsf - 1));
+	}
+	if (sr_hint == 12)
+		put((uint8_t)(P.sample_rate / 1000));
+	else if (sr_hint == 13) {
+		put((uint8_t)(P.sample_rate >> 8));
+		put((uint8_t)P.sample_rate);
+	} else if (sr_hint == 14) {
+		put((uint8_t)((P.sample_rate / 10) >> 8));
+		put((uint8_t)(P.sample_rate / 10));
+	}
+	return n;
+}
+
 struct PkShared {
 	uint32_t W[PK_CAPW] __attribute__((aligned(16)));
 	uint32_t scan[4];
@@ -150,12 +254,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(PkShared &S, uint32_t v
 }
 
 // CRC-16 of nbytes (<= 4 PK_CAPW) bytes that start at window word 0 (FLAC__crc16, crc.c:134).  The
-// bytes are taken as 256 runs of 1, 2, 4, 8 or 16 words, padded with zeros IN FRONT (leading zeros do
+// bytes are taken as 256 runs of 1, 2, 4, 8, 16 or 32 words, padded with zeros IN FRONT (leading zeros do
 // not change a CRC that starts at 0) so that the last run ends with the last byte.  Each thread puts
 // its run through four byte tables at once and multiplies the result by x^(8 * bytes that follow
 // it), a power that comes from a table because the run sizes are fixed; the CRC being linear, the
 // XOR of the 256 products is the answer.  nbytes is the same in all threads.
-__device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
+__device__ __forceinline__ uint32_t window_crc16(const uint32_t *W, const uint16_t (*crc_tables)[256], uint32_t *crcs, uint32_t nbytes)
 {
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint32_t nw = (nbytes + 3) / 4;       // words after padding in front
@@ -170,16 +274,16 @@ __device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
 	const int32_t first = (int32_t)(tid * run) - (int32_t)(FA_THREADS * run - nw);
 	uint32_t crc = 0;
 	if (first + (int32_t)run > 0) {
-		uint32_t prev = first > 0 ? S.W[first - 1] : 0u;
+		uint32_t prev = first > 0 ? W[first - 1] : 0u;
 		for (uint32_t i = 0; i < run; i++) {
 			const int32_t j = first + (int32_t)i;
 			if (j < 0)
 				continue;
-			const uint32_t cur = S.W[j];
+			const uint32_t cur = W[j];
 			const uint32_t v = pad ? (prev << (32 - 8 * pad)) | (cur >> (8 * pad)) : cur;
 			prev = cur;
-			crc = S.crc_tables[3][(v >> 24) ^ (crc >> 8)] ^ S.crc_tables[2][((v >> 16) & 0xff) ^ (crc & 0xff)] ^ S.crc_tables[1][(v >> 8) & 0xff] ^
-			      S.crc_tables[0][v & 0xff];
+			crc = crc_tables[3][(v >> 24) ^ (crc >> 8)] ^ crc_tables[2][((v >> 16) & 0xff) ^ (crc & 0xff)] ^ crc_tables[1][(v >> 8) & 0xff] ^
+			      crc_tables[0][v & 0xff];
 		}
 	}
 	uint32_t part = gf16_mul(crc, my_pow);
@@ -188,9 +292,9 @@ __device__ __forceinline__ uint32_t window_crc16(PkShared &S, uint32_t nbytes)
 		part ^= (uint32_t)__shfl_xor((int)part, o, 64);
 	__syncthreads();
 	if (lane == 0)
-		S.crcs[wv] = part;
+		crcs[wv] = part;
 	__syncthreads();
-	const uint32_t out = S.crcs[0] ^ S.crcs[1] ^ S.crcs[2] ^ S.crcs[3];
+	const uint32_t out = crcs[0] ^ crcs[1] ^ crcs[2] ^ crcs[3];
 	__syncthreads();
 	return out;
 }
@@ -203,7 +307,7 @@ __device__ __forceinline__ void flush_window(PkShared &S, uint32_t *slot, uint32
 {
 	const uint32_t tid = threadIdx.x;
 	if (with_crc && nwords) {
-		const uint32_t c = window_crc16(S, nwords * 4);
+		const uint32_t c = window_crc16(S.W, S.crc_tables, S.crcs, nwords * 4);
 		if (tid == 0)
 			S.frame_crc = gf16_mul(S.frame_crc, gf16_xpow8(nwords * 4)) ^ c;
 	}
@@ -274,14 +378,15 @@ struct PkPlans {
 // written signal is formed from it in registers.
 template <int HIST, bool NARROW, bool QUAD>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pack(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats, const FaPlan *plans,
-                                                     const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps)
+                                                     const uint32_t *assign, uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps,
+                                                     uint32_t first)
 {
 // debugging aid: thread 0's shader clock at point k goes to stamps[block][k]
-#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)f * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 	__shared__ PkShared S;
 	__shared__ PkStage<HIST> T;
 	__shared__ PkPlans PL;
-	const uint32_t f = blockIdx.x, tid = threadIdx.x;
+	const uint32_t f = first + blockIdx.x, tid = threadIdx.x;   // the frames before `first` are k_pack_frame's
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
 	const uint32_t slot_words = P.slot_bytes / 4;
@@ -354,96 +459,11 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 	// ---- frame header: FLAC__frame_add_header (stream_encoder_framing.c:219) ----
 	uint32_t bitpos;
 	{
-		// the header's bytes (at most 16) are collected in two 64-bit words, first byte on top;
 		// everything here is the same in all threads
-		uint64_t hw[2] = {0, 0};
-		uint32_t n = 0;
-		auto put = [&](uint32_t byte) {
-			const uint64_t v = (uint64_t)(byte & 0xff) << (56 - 8 * (n & 7));
-			if (n < 8)
-				hw[0] |= v;
-			else
-				hw[1] |= v;
-			n++;
-		};
-		auto get = [&](uint32_t i) { return (uint32_t)((i < 8 ? hw[0] : hw[1]) >> (56 - 8 * (i & 7))) & 0xff; };
-		put(0xff);
-		put(0xf8);
-		uint32_t u, bs_hint = 0, sr_hint = 0;
-		switch (bsf) {
-		case 192: u = 1; break;
-		case 576: u = 2; break;
-		case 1152: u = 3; break;
-		case 2304: u = 4; break;
-		case 4608: u = 5; break;
-		case 256: u = 8; break;
-		case 512: u = 9; break;
-		case 1024: u = 10; break;
-		case 2048: u = 11; break;
-		case 4096: u = 12; break;
-		case 8192: u = 13; break;
-		case 16384: u = 14; break;
-		case 32768: u = 15; break;
-		default: bs_hint = u = bsf <= 0x100 ? 6 : 7; break;
-		}
-		uint32_t v;
-		switch (P.sample_rate) {
-		case 88200: v = 1; break;
-		case 176400: v = 2; break;
-		case 192000: v = 3; break;
-		case 8000: v = 4; break;
-		case 16000: v = 5; break;
-		case 22050: v = 6; break;
-		case 24000: v = 7; break;
-		case 32000: v = 8; break;
-		case 44100: v = 9; break;
-		case 48000: v = 10; break;
-		case 96000: v = 11; break;
-		default:
-			if (P.sample_rate <= 255000 && P.sample_rate % 1000 == 0) sr_hint = v = 12;
-			else if (P.sample_rate % 10 == 0) sr_hint = v = 14;
-			else if (P.sample_rate <= 0xffff) sr_hint = v = 13;
-			else v = 0;
-			break;
-		}
-		put((uint8_t)((u << 4) | v));
-		const uint32_t chcode = ca == 0 ? P.channels - 1 : 7 + ca;
-		uint32_t bcode;
-		switch (P.bps) {
-		case 8: bcode = 1; break;
-		case 12: bcode = 2; break;
-		case 16: bcode = 4; break;
-		case 20: bcode = 5; break;
-		case 24: bcode = 6; break;
-		default: bcode = 0; break;
-		}
-		put((uint8_t)((chcode << 4) | (bcode << 1)));
-		// FLAC__bitwriter_write_utf8_uint32 (bitwriter.c:784)
-		const uint32_t val = B.first_frame + f;
-		if (val < 0x80)
-			put((uint8_t)val);
-		else {
-			const int cont = val < 0x800 ? 1 : val < 0x10000 ? 2 : val < 0x200000 ? 3 : val < 0x4000000 ? 4 : 5;
-			const uint32_t lead = (0xff00u >> (cont + 1)) & 0xff;  // 0xC0, 0xE0, 0xF0, 0xF8, 0xFC
-			put((uint8_t)(lead | (val >> (6 * cont))));
-			for (int i = cont - 1; i >= 0; i--)
-				put((uint8_t)(0x80 | ((val >> (6 * i)) & 0x3f)));
-		}
-		if (bs_hint == 6)
-			put((uint8_t)(bsf - 1));
-		else if (bs_hint == 7) {
-			put((uint8_t)((bsf - 1) >> 8));
-			put((uint8_t)(bsf - 1));
-		}
-		if (sr_hint == 12)
-			put((uint8_t)(P.sample_rate / 1000));
-		else if (sr_hint == 13) {
-			put((uint8_t)(P.sample_rate >> 8));
-			put((uint8_t)P.sample_rate);
-		} else if (sr_hint == 14) {
-			put((uint8_t)((P.sample_rate / 10) >> 8));
-			put((uint8_t)(P.sample_rate / 10));
-		}
+		uint64_t hw[2];
+		uint32_t n = frame_header_bytes(P, bsf, B.first_frame + f, ca, hw);
+		auto put = [&](uint32_t byte) { hdr_put(hw, n, byte); };
+		auto get = [&](uint32_t i) { return hdr_get(hw, i); };
 		uint8_t crc = 0;  // FLAC__crc8 (crc.c:124)
 		for (uint32_t i = 0; i < n; i++)
 			crc = c_crc8_table[crc ^ get(i)];
@@ -677,7 +697,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 	{
 		const uint32_t bw = S.base_word;
 		const uint32_t tail_bytes = nbytes - bw * 4;
-		const uint32_t c = window_crc16(S, tail_bytes);
+		const uint32_t c = window_crc16(S.W, S.crc_tables, S.crcs, tail_bytes);
 		STAMP(12);
 		if (tid == 0) {
 			const uint32_t crc = gf16_mul(S.frame_crc, gf16_xpow8(tail_bytes)) ^ c;
@@ -696,18 +716,441 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #undef STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_pack_frame: the same frame (process_frame_, stream_encoder.c:2861) for the common shape - full
+// blocks of 16-bit stereo with mid/side evaluated, at most FA_TILE samples, residuals that need 32-bit
+// sums only, Rice partitions that are whole multiples of a thread's sixteen samples - written so that
+// the frame is passed over once.
+//
+// The whole frame's bit stream fits one LDS window, which takes the place of the staged samples once
+// every thread has its own in registers.  Both written subframes are worked out before anything is
+// emitted: a thread keeps the sixteen values it will code for each of them (zigzagged residuals or
+// verbatim samples), one block scan over the pair of lengths places every thread's run of both
+// subframes, and the runs, the subframe headers (whose sizes follow from the plans alone), the warm-up
+// samples, the coefficients and the frame header all go into the window side by side.  A field is
+// positioned with one shift and one v_alignbit_b32 and lands with two ds_or_b32, no conditions: zero
+// bits never need writing and the window was cleared.  CRC-16 and the copy to the frame's slot follow.
+// ---------------------------------------------------------------------------------------------
+#define PQ_CAPW 5184   // words of the window (a C2 slot is 5152 words)
+
+template <int HIST>
+struct PqShared {
+	union {
+		uint32_t W[PQ_CAPW];
+		int32_t T[ST_WORDS(HIST)];
+	} u __attribute__((aligned(16)));
+	uint16_t crc_tables[4][256];
+	uint32_t crcs[4];
+	uint32_t scan[4][2];
+	uint8_t crc8[256] __attribute__((aligned(4)));
+	uint8_t params[4][FA_MAX_PARTS];
+	int32_t q[4][FA_MAX_ORDER];
+	uint4 head[4];   // FaPlan's first words: bits | type, order, precision, shift | part_order, rice2, wide, - | constant
+	uint2 stat[4];   // wasted, subframe bps
+};
+
+// One written subframe, the same in every thread.
+struct PqSub {
+	uint32_t sig, type, order, precision, shift, po, rice2, wasted, sbps;
+	uint32_t hbits;   // bits in front of the first partition's parameter (of the first sample when verbatim)
+	uint32_t plen, psize;
+	uint32_t constant;
+};
+
+template <typename SH>
+__device__ __forceinline__ PqSub pq_sub(const SH &S, uint32_t sig, uint32_t bsf)
+{
+	PqSub D;
+	const uint4 hd = S.head[sig];
+	const uint2 sw = S.stat[sig];
+	const uint32_t h1 = __builtin_amdgcn_readfirstlane(hd.y), h2 = __builtin_amdgcn_readfirstlane(hd.z);
+	D.sig = sig;
+	D.type = h1 & 0xff;
+	D.order = (h1 >> 8) & 0xff;
+	D.precision = (h1 >> 16) & 0xff;
+	D.shift = (uint32_t)(int32_t)(int8_t)(h1 >> 24);
+	D.po = h2 & 0xff;
+	D.rice2 = (h2 >> 8) & 0xff;
+	D.constant = __builtin_amdgcn_readfirstlane(hd.w);
+	D.wasted = __builtin_amdgcn_readfirstlane(sw.x);
+	D.sbps = __builtin_amdgcn_readfirstlane(sw.y);
+	D.plen = D.rice2 ? 5 : 4;
+	D.psize = bsf >> D.po;
+	// FLAC__subframe_add_* (stream_encoder_framing.c:366-479)
+	D.hbits = 8 + D.wasted;
+	if (D.type == FA_SUB_CONSTANT)
+		D.hbits += D.sbps;
+	else if (D.type == FA_SUB_FIXED)
+		D.hbits += D.order * D.sbps + 6;
+	else if (D.type == FA_SUB_LPC)
+		D.hbits += D.order * (D.sbps + D.precision) + 9 + 6;
+	return D;
+}
+
+// OR a field into the window at bit position q, most significant bit first; vh holds the field's bits
+// left-aligned with zeros behind them.  The caller has made sure that q / 32 + 1 is inside the window.
+__device__ __forceinline__ void pq_emit(uint32_t *W, uint32_t q, uint32_t vh)
+{
+	const uint32_t sh = q & 31u;
+	uint32_t *p = W + (q >> 5);
+	atomicOr(p, vh >> sh);
+	atomicOr(p + 1, __builtin_amdgcn_alignbit(vh, 0u, sh));
+}
+
+__device__ __forceinline__ uint32_t pq_mask(uint32_t n) { return n >= 32 ? 0xffffffffu : (1u << n) - 1u; }
+
+// What the thread codes for its sixteen samples of a subframe (uz: the zigzagged residual, or the sample
+// itself when verbatim) from the staged stereo words, and the length of its run in bits.  k: the Rice
+// parameter of the partition the samples lie in; pstart: they are its first, so the parameter precedes them.
+template <int HIST>
+__device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHUNK], const PqSub &D, const int32_t *qv, uint32_t base, uint32_t k, bool pstart,
+                                              uint32_t (&uz)[FA_CHUNK])
+{
+	// mid = (L+R)>>1, side = L-R (stream_encoder.c:1991-1992), minus the wasted bits
+	int32_t d[HIST + FA_CHUNK];
+	switch (D.sig) {
+	case 0:
+#pragma unroll
+		for (int j = 0; j < HIST + FA_CHUNK; j++)
+			d[j] = (int32_t)(int16_t)((uint32_t)raw[j] & 0xffff);
+		break;
+	case 1:
+#pragma unroll
+		for (int j = 0; j < HIST + FA_CHUNK; j++)
+			d[j] = raw[j] >> 16;
+		break;
+	case 2:
+#pragma unroll
+		for (int j = 0; j < HIST + FA_CHUNK; j++)
+			d[j] = ((int32_t)(int16_t)((uint32_t)raw[j] & 0xffff) + (raw[j] >> 16)) >> 1;
+		break;
+	default:
+#pragma unroll
+		for (int j = 0; j < HIST + FA_CHUNK; j++)
+			d[j] = (int32_t)(int16_t)((uint32_t)raw[j] & 0xffff) - (raw[j] >> 16);
+		break;
+	}
+	if (D.wasted) {
+#pragma unroll
+		for (int j = 0; j < HIST + FA_CHUNK; j++)
+			d[j] >>= D.wasted;
+	}
+	if (D.type == FA_SUB_VERBATIM) {
+		const uint32_t mask = pq_mask(D.sbps);
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++)
+			uz[i] = (uint32_t)d[HIST + i] & mask;
+		return FA_CHUNK * D.sbps;
+	}
+	int32_t res[FA_CHUNK];
+	if (D.type == FA_SUB_FIXED)
+		fixed_residual16<HIST>(d, D.order, res);
+	else
+		lpc_residual16_any<HIST, true>(d, qv, D.order, (int)D.shift, 0, res);
+	uint32_t nb = pstart ? D.plen : 0u;
+	const uint32_t k1 = k + 1u;
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++) {
+		uz[i] = ((uint32_t)res[i] << 1) ^ (uint32_t)(res[i] >> 31);
+		const bool coded = base + (uint32_t)i >= D.order;   // the frame's first `order` samples are the warm-up
+		nb += coded ? (uz[i] >> k) + k1 : 0u;
+	}
+	return nb;
+}
+
+// The thread's run of a subframe into the window from bit p on (FLAC__bitwriter_write_rice_signed_block,
+// bitwriter.c:544; verbatim samples: stream_encoder_framing.c:466).
+__device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint32_t (&uz)[FA_CHUNK], uint32_t base, uint32_t k, bool pstart, uint32_t p)
+{
+	if (D.type == FA_SUB_VERBATIM) {
+		const uint32_t lsh = 32u - D.sbps;
+#pragma unroll
+		for (int i = 0; i < FA_CHUNK; i++) {
+			pq_emit(W, p, uz[i] << lsh);
+			p += D.sbps;
+		}
+		return;
+	}
+	if (pstart) {
+		pq_emit(W, p, k << (32u - D.plen));
+		p += D.plen;
+	}
+	const uint32_t kmask = (1u << k) - 1u, stop = 1u << k, lsh = 31u - k, k1 = k + 1u;
+#pragma unroll
+	for (int i = 0; i < FA_CHUNK; i++) {
+		const bool coded = base + (uint32_t)i >= D.order;
+		const uint32_t q = p + (uz[i] >> k);
+		const uint32_t vh = ((uz[i] & kmask) | stop) << lsh;
+		pq_emit(W, coded ? q : p, coded ? vh : 0u);
+		p = coded ? q + k1 : p;
+	}
+}
+
+template <int HIST>
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaPlan *__restrict__ plans,
+                  const uint32_t *__restrict__ assign, uint32_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, uint32_t *errflag)
+{
+	__shared__ PqShared<HIST> S;
+	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t bsf = P.blocksize;   // full frames only
+	const uint64_t frame_start = (uint64_t)f * bsf;
+	const uint32_t slot_words = P.slot_bytes / 4;
+	uint32_t *slot = slots + (size_t)f * slot_words;
+	constexpr uint32_t HP = ST_HP(HIST);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	const uint32_t *words = (const uint32_t *)pcm + frame_start;
+
+	// ---- everything the frame needs from global memory, requested in one go ----
+	{
+		uint32_t pre_w[NIT];
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			int32_t idx = (int32_t)j - (int32_t)HP;
+			idx = idx < 0 ? 0 : ((uint32_t)idx >= bsf ? (int32_t)bsf - 1 : idx);
+			pre_w[i] = words[idx];
+		}
+		const FaPlan *fp = plans + (size_t)f * 4;
+		uint8_t pre_params[4];
+		int32_t pre_q[4] = {0, 0, 0, 0};
+		uint4 pre_head = {0, 0, 0, 0};
+		uint2 pre_stat = {0, 0};
+#pragma unroll
+		for (int sg = 0; sg < 4; sg++) {
+			pre_params[sg] = fp[sg].params[tid];
+			if (tid < FA_MAX_ORDER)
+				pre_q[sg] = fp[sg].q[tid];
+		}
+		if (tid < 4) {
+			pre_head = *(const uint4 *)(fp + tid);
+			pre_stat.x = stats[(size_t)f * 4 + tid].wasted;
+			pre_stat.y = stats[(size_t)f * 4 + tid].bps;
+		}
+		for (uint32_t e = tid; e < 4 * 256 / 2; e += FA_THREADS)
+			((uint32_t *)&S.crc_tables[0][0])[e] = ((const uint32_t *)&c_crc16x4[0][0])[e];
+		if (tid < 64)
+			((uint32_t *)S.crc8)[tid] = ((const uint32_t *)c_crc8_table)[tid];
+#pragma unroll
+		for (int sg = 0; sg < 4; sg++) {
+			S.params[sg][tid] = pre_params[sg];
+			if (tid < FA_MAX_ORDER)
+				S.q[sg][tid] = pre_q[sg];
+		}
+		if (tid < 4) {
+			S.head[tid] = pre_head;
+			S.stat[tid] = pre_stat;
+		}
+		const uint32_t n0 = HP + bsf;   // (a multiple of 16)
+#pragma unroll
+		for (uint32_t i = 0; i < NIT; i++) {
+			const uint32_t j = tid + i * FA_THREADS;
+			if (j < n0)
+				S.u.T[j + (j >> 4)] = j >= HP ? (int32_t)pre_w[i] : 0;
+		}
+	}
+	const uint32_t ca = __builtin_amdgcn_readfirstlane(assign[f]);
+	__syncthreads();
+
+	// ---- the two subframes in written order (stream_encoder.c:3091-3151) ----
+	uint32_t sig0 = 0, sig1 = 1;
+	if (ca == 1) sig1 = 3;                    // left, side
+	else if (ca == 2) sig0 = 3;               // side, right
+	else if (ca == 3) { sig0 = 2; sig1 = 3; } // mid, side
+	const PqSub D0 = pq_sub(S, sig0, bsf), D1 = pq_sub(S, sig1, bsf);
+
+	const uint32_t base = tid * FA_CHUNK;
+	const bool have = base < bsf;
+	uint32_t uz0[FA_CHUNK], uz1[FA_CHUNK];
+	uint32_t nb0 = 0, nb1 = 0, k0 = 0, k1 = 0;
+	bool ps0 = false, ps1 = false;
+	uint32_t warm = 0;   // waves 0 and 1: warm-up sample `lane` of subframe 0 / 1
+	{
+		int32_t raw[HIST + FA_CHUNK];
+		if (have)
+			load_chunk_lds<HIST>(raw, S.u.T);
+		if (wv < 2) {
+			const PqSub &D = wv == 0 ? D0 : D1;
+			if (lane < D.order) {
+				const uint32_t j = HP + lane;
+				warm = (uint32_t)(quad_signal((uint32_t)S.u.T[j + (j >> 4)], D.sig) >> D.wasted);
+			}
+		}
+		if (have && D0.type != FA_SUB_CONSTANT) {
+			if (D0.type != FA_SUB_VERBATIM) {
+				const uint32_t part = base / D0.psize;
+				k0 = S.params[sig0][part];
+				ps0 = base == part * D0.psize;
+			}
+			nb0 = pq_values<HIST>(raw, D0, S.q[sig0], base, k0, ps0, uz0);
+		}
+		if (have && D1.type != FA_SUB_CONSTANT) {
+			if (D1.type != FA_SUB_VERBATIM) {
+				const uint32_t part = base / D1.psize;
+				k1 = S.params[sig1][part];
+				ps1 = base == part * D1.psize;
+			}
+			nb1 = pq_values<HIST>(raw, D1, S.q[sig1], base, k1, ps1, uz1);
+		}
+	}
+
+	// ---- where every run starts: one block scan over the pair of lengths ----
+	const uint32_t in0 = sw_scan_incl(nb0), in1 = sw_scan_incl(nb1);
+	if (lane == 63) {
+		S.scan[wv][0] = in0;
+		S.scan[wv][1] = in1;
+	}
+	__syncthreads();   // (also: every thread has read what it needs of the staged samples)
+	uint32_t off0 = 0, off1 = 0, total0 = 0, total1 = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 4; w++) {
+		const uint32_t a = __builtin_amdgcn_readfirstlane(S.scan[w][0]), b = __builtin_amdgcn_readfirstlane(S.scan[w][1]);
+		off0 += w < wv ? a : 0u;
+		off1 += w < wv ? b : 0u;
+		total0 += a;
+		total1 += b;
+	}
+	// FLAC__frame_add_header (stream_encoder_framing.c:219); its CRC-8 is one more byte
+	uint64_t hw[2];
+	uint32_t hn = frame_header_bytes(P, bsf, B.first_frame + f, ca, hw);
+	const uint32_t pos0 = 8 * (hn + 1);
+	const uint32_t pos1 = pos0 + D0.hbits + total0;
+	const uint32_t bitpos = pos1 + D1.hbits + total1;
+	const uint32_t nbytes = (bitpos + 7) >> 3;           // zero padding to a whole byte (stream_encoder.c:2885)
+	const uint32_t total_words = (nbytes + 2 + 3) / 4;   // with the CRC-16
+	const uint32_t cap = slot_words < PQ_CAPW ? slot_words : PQ_CAPW;
+	if (total_words + 2 > cap) {
+		// (cannot happen while the slot is sized as slot_bytes_for sizes it; loud if it ever does)
+		if (tid == 0) {
+			atomicOr(errflag, 1u);
+			frame_bytes[f] = 0;
+		}
+		return;
+	}
+	uint32_t *W = S.u.W;
+	for (uint32_t i = tid; i < (total_words + 2 + 3) / 4; i += FA_THREADS)
+		((uint4 *)W)[i] = make_uint4(0, 0, 0, 0);
+	__syncthreads();
+
+	// ---- everything into the window ----
+	if (have) {
+		if (D0.type != FA_SUB_CONSTANT)
+			pq_codes(W, D0, uz0, base, k0, ps0, pos0 + D0.hbits + off0 + (in0 - nb0));
+		if (D1.type != FA_SUB_CONSTANT)
+			pq_codes(W, D1, uz1, base, k1, ps1, pos1 + D1.hbits + off1 + (in1 - nb1));
+	}
+	{
+		// subframe headers (stream_encoder_framing.c:366-479): waves 0 and 1 write the warm-up samples and
+		// the small fields of subframe 0 and 1, waves 2 and 3 their coefficients
+		const PqSub &D = (wv & 1u) == 0 ? D0 : D1;
+		const uint32_t pos = (wv & 1u) == 0 ? pos0 : pos1;
+		const bool predicted = D.type == FA_SUB_FIXED || D.type == FA_SUB_LPC;
+		const uint32_t after_warm = pos + 8 + D.wasted + D.order * D.sbps;
+		if (wv < 2) {
+			if (predicted && lane < D.order)
+				pq_emit(W, pos + 8 + D.wasted + lane * D.sbps, (warm & pq_mask(D.sbps)) << (32u - D.sbps));
+			if (lane == 63) {
+				uint32_t typebits;
+				switch (D.type) {
+				case FA_SUB_CONSTANT: typebits = 0x00; break;
+				case FA_SUB_VERBATIM: typebits = 0x02; break;
+				case FA_SUB_FIXED: typebits = 0x10 | (D.order << 1); break;
+				default: typebits = 0x40 | ((D.order - 1) << 1); break;
+				}
+				pq_emit(W, pos, (typebits | (D.wasted ? 1u : 0u)) << 24);
+				if (D.wasted)
+					pq_emit(W, pos + 8 + D.wasted - 1, 0x80000000u);
+				if (D.type == FA_SUB_CONSTANT)
+					pq_emit(W, pos + 8 + D.wasted, (D.constant & pq_mask(D.sbps)) << (32u - D.sbps));
+				if (D.type == FA_SUB_LPC)
+					pq_emit(W, after_warm, (((D.precision - 1u) << 5) | (D.shift & 31u)) << 23);
+				if (predicted)
+					pq_emit(W, pos + D.hbits - 6, (((D.rice2 ? 1u : 0u) << 4) | D.po) << 26);
+			}
+		} else if (D.type == FA_SUB_LPC && lane < D.order)
+			pq_emit(W, after_warm + 9 + lane * D.precision, ((uint32_t)S.q[D.sig][lane] & pq_mask(D.precision)) << (32u - D.precision));
+	}
+	if (tid == FA_THREADS - 1) {
+		uint32_t crc = 0;  // FLAC__crc8 (crc.c:124)
+		for (uint32_t i = 0; i < hn; i++)
+			crc = S.crc8[crc ^ hdr_get(hw, i)];
+		hdr_put(hw, hn, crc);
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++)
+			if (4 * i < hn)
+				pq_emit(W, 32 * i, (uint32_t)(hw[i >> 1] >> ((i & 1u) ? 0 : 32)));   // (the bytes behind the header read as zero)
+	}
+	__syncthreads();
+
+	// ---- CRC-16 over everything so far (stream_encoder.c:2890-2900), then out to the frame's slot ----
+	const uint32_t crc16 = window_crc16(W, S.crc_tables, S.crcs, nbytes);
+	if (tid == 0)
+		pq_emit(W, nbytes * 8, crc16 << 16);
+	__syncthreads();
+	for (uint32_t i = tid; i < (total_words + 3) / 4; i += FA_THREADS) {
+		uint4 v = ((const uint4 *)W)[i];
+		v.x = __builtin_bswap32(v.x);
+		v.y = __builtin_bswap32(v.y);
+		v.z = __builtin_bswap32(v.z);
+		v.w = __builtin_bswap32(v.w);
+		((uint4 *)slot)[i] = v;
+	}
+	if (tid == 0)
+		frame_bytes[f] = nbytes + 2;
+}
+
+// Whether k_pack_frame can write this stream's full frames (the short last one stays with k_pack).
+static bool pack_frame_eligible(const FaEncParams &P, const FaBatch &B)
+{
+	if (!(B.pairs && P.nsignals == 4 && fa_narrow_only(P)))
+		return false;
+	if (P.blocksize > FA_TILE || P.blocksize % FA_CHUNK)
+		return false;
+	// the smallest partition a full block can be cut into (stream_encoder.c:2929-2936) is whole chunks
+	uint32_t reach = 0;
+	while (reach < P.max_po && !((P.blocksize >> reach) & 1u))
+		reach++;
+	if ((P.blocksize >> reach) % FA_CHUNK)
+		return false;
+	return P.slot_bytes / 4 <= PQ_CAPW;
+}
+
 void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
                     uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st)
 {
-	const dim3 grid(B.nframes), block(FA_THREADS);
-#define PACK_LAUNCH(H, N) \
-	do { \
-		if (quad) hipLaunchKernelGGL((k_pack<H, N, true>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps); \
-		else hipLaunchKernelGGL((k_pack<H, N, false>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps); \
-	} while (0)
+	const dim3 block(FA_THREADS);
 	const bool narrow = fa_narrow_only(P);
 	const bool quad = B.pairs && P.nsignals == 4;
-	switch (fa_hist_class(P)) {
+	const int hist = fa_hist_class(P);
+	// Full frames of the common shape go to k_pack_frame (FLAC_AMD_PACK=generic keeps every frame on k_pack, for
+	// comparisons); first: the first frame k_pack still has to write.
+	uint32_t first = 0;
+	{
+		const char *mode = getenv("FLAC_AMD_PACK");
+		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
+		uint64_t nfull = B.wide_samples / P.blocksize;
+		if (nfull > B.nframes)
+			nfull = B.nframes;
+		if (!generic_only && nfull && pack_frame_eligible(P, B)) {
+			const dim3 grid((uint32_t)nfull);
+			switch (hist) {
+			case 4: hipLaunchKernelGGL(k_pack_frame<4>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
+			case 12: hipLaunchKernelGGL(k_pack_frame<12>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
+			default: hipLaunchKernelGGL(k_pack_frame<32>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
+			}
+			first = (uint32_t)nfull;
+		}
+	}
+	if (first >= B.nframes)
+		return;
+	const dim3 grid(B.nframes - first);
+#define PACK_LAUNCH(H, N) \
+	do { \
+		if (quad) hipLaunchKernelGGL((k_pack<H, N, true>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps, first); \
+		else hipLaunchKernelGGL((k_pack<H, N, false>), grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, stamps, first); \
+	} while (0)
+	switch (hist) {
 	case 4: PACK_LAUNCH(4, true); break;
 	case 12: if (narrow) PACK_LAUNCH(12, true); else PACK_LAUNCH(12, false); break;
 	default: if (narrow) PACK_LAUNCH(32, true); else PACK_LAUNCH(32, false); break;

@@ -1,0 +1,99 @@
+"""The frame writer has two forms on the device: k_pack (any stream; a window of the frame's bits that
+slides, one subframe after the other) and k_pack_frame (full blocks of 16-bit stereo with mid/side,
+the benchmark's shape; the whole frame in one window, both subframes in one pass).  Both restate
+process_frame_'s output (stream_encoder.c:2861: frame header, subframes, padding, CRC-16) for plans the
+model search has made, so they must write the same bytes.  The golden cases pin whichever form their
+shape selects to the reference's bytes; this test holds the two forms against each other on signals and
+settings the golden set does not have at these block sizes: full-scale noise (verbatim subframes, the
+longest frames there are), square waves (very long Rice codes next to very short ones), wasted bits,
+constant and silent blocks, every channel assignment, Rice parameters above 14, partition-order
+limits, fixed-only presets, block sizes below 4096, frame numbers whose UTF-8 form is one to five
+bytes, and a short last block (which stays with k_pack)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_search_forms import signals
+
+pytestmark = pytest.mark.gpu
+
+
+SETTINGS = [
+    ("level1_loose", 1, {}),
+    ("level2_fixed", 2, {}),
+    ("level5", 5, {}),
+    ("level8", 8, {}),
+    ("level8_po66", 8, {"min_residual_partition_order": 6, "max_residual_partition_order": 6}),
+    ("level8_po0", 8, {"min_residual_partition_order": 0, "max_residual_partition_order": 0}),
+    ("level8_po8", 8, {"max_residual_partition_order": 8}),
+    ("level8_prec12", 8, {"qlp_coeff_precision": 12}),
+    ("level8_noverbatim", 8, {"disable_verbatim_subframes": 1}),
+    ("level8_noconstant", 8, {"disable_constant_subframes": 1}),
+]
+
+
+def encode(params, pcm, form, first_frame=0):
+    import flac_amd
+    if form == "generic":
+        os.environ["FLAC_AMD_PACK"] = "generic"
+    else:
+        os.environ.pop("FLAC_AMD_PACK", None)
+    try:
+        enc = flac_amd.Encoder(params, device=0, max_frames=64)
+        try:
+            frames, _ = enc.encode_host(pcm, first_frame=first_frame)
+        finally:
+            enc.close()
+    finally:
+        os.environ.pop("FLAC_AMD_PACK", None)
+    return frames
+
+
+@pytest.mark.parametrize("bs", [4096, 2048, 1024, 512, 256])
+def test_frame_form_writes_what_the_window_form_writes(bs):
+    import flac_amd
+    sigs = signals(16, 2)
+    for sname, level, over in SETTINGS:
+        p = flac_amd.preset(level, 2, 16, 44100, bs, **over)
+        assert p.blocksize == bs
+        for name, pcm in sigs.items():
+            pcm = pcm[:bs * 4 + bs // 3]
+            a = encode(p, pcm, "generic")
+            b = encode(p, pcm, "frame")
+            assert len(a) == len(b) == 5
+            for i, (fa, fb) in enumerate(zip(a, b)):
+                assert fa == fb, "%s / %s / blocks of %d: frame %d differs between the two forms" % (sname, name, bs, i)
+
+
+@pytest.mark.parametrize("first_frame", [0, 0x7f, 0x7fe, 0xfffe, 0x1ffffe, 0x3fffffe])
+def test_frame_numbers_of_every_length(first_frame):
+    import flac_amd
+    pcm = signals(16, 2)["music"]
+    p = flac_amd.preset(8, 2, 16, 44100, 4096)
+    a = encode(p, pcm, "generic", first_frame)
+    b = encode(p, pcm, "frame", first_frame)
+    assert a == b
+
+
+def test_odd_sample_rates():
+    import flac_amd
+    pcm = signals(16, 2)["music"]
+    for rate in (44100, 96000, 11025, 12345, 65535, 655350, 64000):
+        p = flac_amd.preset(8, 2, 16, rate, 4096)
+        assert encode(p, pcm, "generic") == encode(p, pcm, "frame"), rate
+
+
+def test_frame_form_against_the_oracle():
+    """The same signals through the CPU restatement of the reference: the frame form's bytes are the
+    reference's, not merely the other form's."""
+    import flac_amd
+    import oracle_lib as O
+    sigs = signals(16, 2)
+    for level in (5, 8):
+        p = flac_amd.preset(level, 2, 16, 44100, 4096)
+        op = O.preset(level, 2, 16, 44100, 4096)
+        for name, pcm in sigs.items():
+            got = encode(p, pcm, "frame")
+            want, _ = O.encode_frames(op, pcm)
+            assert got == list(want), (level, name)
