@@ -186,6 +186,12 @@ class Encoder:
         return buf
 
 
+class FrameInfo(C.Structure):
+    """flacamd_frame_info"""
+    _fields_ = [("pos", C.c_uint64), ("sample", C.c_uint64), ("end_byte", C.c_uint64), ("hdr_bytes", C.c_uint32), ("blocksize", C.c_uint32),
+                ("assignment", C.c_uint32), ("stream", C.c_uint32), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Decoder:
     """Batch frame decoder bound to one GPU; every stream shares channels / bits / max blocksize."""
 
@@ -230,6 +236,13 @@ class Decoder:
         frames, wide, bad = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
         _check(lib().flacamd_decoder_result(self._h, C.byref(frames), C.byref(wide), C.byref(bad)))
         return frames.value, wide.value, bad.value
+
+    def frames(self, capacity=1 << 16):
+        """flacamd_decoder_frames: one FrameInfo per frame header the last decode found, in byte order."""
+        rows = (FrameInfo * capacity)()
+        count, truncated = C.c_uint32(0), C.c_int(0)
+        _check(lib().flacamd_decoder_frames(self._h, rows, capacity, C.byref(count), C.byref(truncated)))
+        return [rows[i] for i in range(count.value)]
 
     def set_profiling(self, on):
         _check(lib().flacamd_decoder_set_profiling(self._h, 1 if on else 0))

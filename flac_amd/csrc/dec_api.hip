@@ -30,6 +30,8 @@ struct flacamd_decoder {
 	int32_t *vals;                  // cooperative form: values per (frame, channel) as read from the stream
 	FaSubDesc *subs;                // cooperative form: what the restore pass needs per (frame, channel)
 	uint32_t coop, coop_lw;         // the cooperative form is used, and its frames per group
+	uint64_t *sub_start;            // split form: bit position at which each (frame, channel)'s subframe starts
+	uint32_t split, skip_lw;        // the split form (walk, then a lane per subframe) is used; frames per wave of its walk
 	unsigned long long *result;     // good frames, wide samples, bad candidates
 	int profiling, have_times;
 	hipEvent_t ev[FLACAMD_DEC_STAGES + 1];
@@ -53,6 +55,7 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipFree(d->tmp);
 	(void)hipFree(d->vals);
 	(void)hipFree(d->subs);
+	(void)hipFree(d->sub_start);
 	(void)hipFree(d->result);
 	(void)hipFree(d->stage_in);
 	(void)hipFree(d->stage_out);
@@ -111,17 +114,42 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
 	ALLOC(d->ncand, 16);
 	ALLOC(d->tmp, sizeof(int32_t) * groups * 64 * channels * max_blocksize);
-	// frames per wave: few frames are spread thin over many waves (about two per SIMD of the chip)
+	// frames per wave: few frames are spread thin over many waves (about two per SIMD of the chip).  While
+	// the batch leaves the chip room, frames with two or more channels are decoded in the split form, a walk that
+	// finds where every subframe starts and then a lane per subframe (FLAC_AMD_DEC_MODE=lane keeps a lane per frame,
+	// =split forces the split form, for comparisons).  The walk costs about half of what decoding the same samples
+	// costs, so a batch large enough to fill the chip with whole frames is better off without it: measured
+	// (tools/dec_mode_probe.py), the split form wins up to about 24 000 subframes (16-bit stereo: 1.56 -> 1.20 ms for
+	// 6 460 frames; eight channels of 24 bits: 6.6 -> 4.4 ms for 2 813 frames) and loses beyond (16 384 stereo
+	// frames: 1.71 -> 1.91 ms).
 	{
+		const char *mode = getenv("FLAC_AMD_DEC_MODE");
+		const uint64_t units = (uint64_t)max_frames * channels;
+		d->split = channels >= 2 && units <= 24000 && !(mode && (!strcmp(mode, "lane") || !strcmp(mode, "coop")));
+		if (mode && !strcmp(mode, "split") && channels >= 2)
+			d->split = 1;
 		uint32_t lw = 4;
-		while (lw < 16 && (max_frames + lw - 1) / lw > 2048)
-			lw *= 2;
+		if (d->split)
+			lw = units <= 8 * 3000 ? 8 : 16;
+		else
+			while (lw < 16 && (max_frames + lw - 1) / lw > 2048)
+				lw *= 2;
+		if (d->split)
+			ALLOC(d->sub_start, sizeof(uint64_t) * (size_t)max_frames * channels);
 		if (const char *env = getenv("FLAC_AMD_DEC_LW")) {
 			const uint32_t v = (uint32_t)atoi(env);
 			if (v >= 1 && v <= 16 && (v & (v - 1)) == 0)
 				lw = v;
 		}
 		d->lw = lw;
+		// the walk of the split form: a lane per frame again, thin enough for the input pump to keep every lane fed
+		uint32_t slw = 8;
+		if (const char *env = getenv("FLAC_AMD_DEC_SKIP_LW")) {
+			const uint32_t v = (uint32_t)atoi(env);
+			if (v >= 1 && v <= 16 && (v & (v - 1)) == 0)
+				slw = v;
+		}
+		d->skip_lw = slw;
 	}
 	ALLOC(d->result, 32);
 	// The cooperative form (dec_coop.hip: a wave per frame, then a lane per subframe) is an opt-in variant,
@@ -231,6 +259,8 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.max_frames = d->max_frames;
 	P.number_scale = d->number_scale;
 	P.lw = d->coop ? d->coop_lw : d->lw;
+	P.skip_lw = d->skip_lw;
+	P.pad = 0;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	const bool prof = d->profiling != 0;
@@ -248,7 +278,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	if (d->coop)
 		fa_dec_launch_coop(P, flac_dev, d->streams, d->cands, d->ncand, d->vals, d->subs, d->tmp, st);
 	else
-		fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, st);
+		fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->split ? d->sub_start : nullptr, st);
 	STAGE_MARK();
 	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, st);
 	STAGE_MARK();

@@ -11,6 +11,8 @@ struct FaDecParams {
 	uint32_t nstreams, max_frames;
 	uint32_t number_scale;   // samples per frame number in fixed-blocksize headers
 	uint32_t lw;             // frames per wave in k_dec_frames and per group in the scratch planes (power of two <= 64)
+	uint32_t skip_lw;        // frames per wave in the walk of the split form (which does not touch the planes)
+	uint32_t pad;
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
 };
@@ -49,8 +51,10 @@ hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, cons
 uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
 void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
                         FaFrameCand *cands, uint32_t *ncand, hipStream_t st);
+// sub_start: null for a lane per frame; else max_frames * channels words for the split form (a walk that leaves
+// where every subframe starts, then a lane per subframe)
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, hipStream_t st);
+                          int32_t *tmp, uint64_t *sub_start, hipStream_t st);
 // the cooperative form for batches of few frames (dec_coop.hip): entropy pass + restore pass in place of fa_dec_launch_frames
 uint32_t fa_dec_coop_lw(uint32_t channels);
 void fa_dec_launch_coop(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *vals,

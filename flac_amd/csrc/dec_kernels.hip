@@ -578,7 +578,9 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 //
 // Samples, shifted back up by the wasted bits (stream_decoder.c:2511-2515), are collected a block
 // at a time in LDS and written to plane[sample * LW + lane] by all threads together.
-template <int M, bool WIDE, bool MUL24>
+// SKIP: the subframe is only walked through, to find where it ends: symbols are measured, not turned into
+// values, nothing is predicted or stored (M is 0).
+template <int M, bool WIDE, bool MUL24, bool SKIP = false>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, DecLds &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
                                                uint32_t bsf, bool live, uint64_t nwords)
 {
@@ -611,13 +613,21 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		}
 		// the fast path takes at most one word per sample
 		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
+		// SKIP: a sample is half a dozen instructions, fewer cycles than an LDS read takes, so the ring is read two
+		// words ahead of the pair in use: n2 and n3 are the words after nxt, n3 requested a step before it can be
+		// needed (garbage while the ring has not got that far, which is when fast_end is 0 and nothing uses them)
+		uint32_t n2 = 0, n3 = 0;
+		if (SKIP) {
+			n2 = r.ring[r.wrel & (RING_WORDS - 1)];
+			n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+		}
 		// unrolled in full: the history needs no moves at all, and the compiler schedules across samples
 		// (unrolled by four: 1.70 ms for the benchmark's frames, in full: 1.63)
 #pragma unroll
 		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
 			const uint32_t i = i0 + s;
 			// the word a step into the next word at the end of this sample would bring in
-			const uint32_t ring_word = r.ring[r.wrel & (RING_WORDS - 1)];
+			const uint32_t ring_word = SKIP ? n2 : r.ring[r.wrel & (RING_WORDS - 1)];
 			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the next 32 bits: count of
 			// leading zeros (all ones for "none of the 32 is set": the saturating add then fails the length test),
 			// stop bit, k low bits
@@ -638,6 +648,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				r.nxt = cross ? ring_word : r.nxt;
 				r.wrel += cross ? 1u : 0u;
 				r.rem = (uint32_t)left & 31u;
+				if (SKIP) {
+					n2 = cross ? n3 : n2;
+					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+				}
 			}
 			if (!fast && i < work_end) {
 				if (h.kind >= 2) {
@@ -681,6 +695,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					seg_end = 0;
 				}
 				fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
+				if (SKIP) {
+					n2 = r.ring[r.wrel & (RING_WORDS - 1)];
+					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+				}
 			}
 			int32_t v = res;
 			if (M > 0) {
@@ -719,28 +737,47 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					hist[j] = hist[j - 1];
 				hist[0] = v;
 			}
-			slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
+			if (!SKIP)
+				slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
 		}
-		// the block goes out with all 64 threads along memory order
-		const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
-		for (uint32_t e = tid; e < nblk; e += DEC_LANES)
-			plane[(size_t)i0 * LW + e] = L.out[e];
+		if (!SKIP) {
+			// the block goes out with all 64 threads along memory order
+			const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
+			for (uint32_t e = tid; e < nblk; e += DEC_LANES)
+				plane[(size_t)i0 * LW + e] = L.out[e];
+		}
 	}
 }
 
 // One lane per frame; a wave carries LW <= 16 frames in its first lanes, the other lanes only help
 // moving data.  A wave's pace is set by its longest dependent chain, not by how many of its lanes
 // decode, so a batch is spread over as many waves as the chip can run at once.
+//
+// The chain is a frame's samples one after the other, and a subframe can only be started where the one
+// before it ends.  For batches that leave the chip room, the chain is cut: DEC_SKIP walks the subframes
+// of every channel but the last without decoding them (a symbol's length is all it takes: a quarter of
+// the instructions) and leaves the bit position at which each subframe starts; DEC_SUB then runs one lane
+// per (frame, channel), a wave taking one channel of LW frames, so the longest chain is one subframe.
+// A frame the walk found malformed gets its status there and is left alone by DEC_SUB; the lane of the
+// last channel finishes the frame (padding, end, status) as the single pass does.
+#define DEC_WHOLE 0
+#define DEC_SKIP 1
+#define DEC_SUB 2
+#define DEC_NO_START 0xffffffffffffffffull
+
+template <int MODE>
 __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
-                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW)
+                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start)
 {
 	__shared__ DecLds L;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ncand = ncand_ptr[0];
-	if (blockIdx.x * LW >= ncand)
+	const uint32_t grp = MODE == DEC_SUB ? blockIdx.x / P.channels : blockIdx.x;
+	const uint32_t only_c = MODE == DEC_SUB ? blockIdx.x % P.channels : 0;
+	if (grp * LW >= ncand)
 		return;
-	const uint32_t j = blockIdx.x * LW + tid;
-	const bool live = tid < LW && j < ncand;
+	const uint32_t j = grp * LW + tid;
+	bool live = tid < LW && j < ncand;
 	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
 	FaFrameCand cd;
 	if (live)
@@ -748,9 +785,21 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	else {
 		cd.pos = 0; cd.sample = 0; cd.hdr_bytes = 0; cd.blocksize = 0; cd.assignment = 0; cd.stream = 0; cd.status = 0; cd.end_byte = 0;
 	}
+	// where the lane starts reading, in bits from the start of the input
+	uint64_t start_bit = (cd.pos + cd.hdr_bytes) * 8;
+	if (MODE == DEC_SUB) {
+		if (live) {
+			start_bit = sub_start[(size_t)j * P.channels + only_c];
+			if (start_bit == DEC_NO_START) {
+				live = false;
+				start_bit = 0;
+			}
+		} else
+			start_bit = 0;
+	}
 	const uint64_t nwords = (P.flac_bytes + 3) / 4;
 	BitRd r;
-	r.wbase = cd.pos >> 2;
+	r.wbase = MODE == DEC_SUB ? start_bit >> 5 : cd.pos >> 2;
 	r.wg = flac_words + r.wbase;
 	r.nrel = nwords - r.wbase > 0xffffffffull ? 0xffffffffu : (uint32_t)(nwords - r.wbase);
 	// positions are 32-bit, relative to the frame's first word; a stream that goes on for more
@@ -786,7 +835,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	pm.lane[0] = pm.lane[1] = -1;
 	pm.data[0] = pm.data[1] = 0;
 	pm.half[0] = pm.half[1] = 0;
-	br_start(r, ((uint32_t)cd.pos & 3) * 8 + cd.hdr_bytes * 8);
+	br_start(r, (uint32_t)(start_bit - r.wbase * 32));
 	const uint32_t bsf = cd.blocksize;
 	uint32_t bs_w = bsf;
 #pragma unroll
@@ -794,11 +843,15 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		const uint32_t t = __shfl_xor(bs_w, o, 64);
 		bs_w = t > bs_w ? t : bs_w;
 	}
-	int32_t *frame_tmp = tmp + (size_t)blockIdx.x * P.channels * P.max_blocksize * LW;
+	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * LW;
 	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
 
-	for (uint32_t c = 0; c < P.channels; c++) {
+	const uint32_t c_first = MODE == DEC_SUB ? only_c : 0;
+	const uint32_t c_end = MODE == DEC_SUB ? only_c + 1 : MODE == DEC_SKIP ? P.channels - 1 : P.channels;
+	for (uint32_t c = c_first; c < c_end; c++) {
 		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
+		if (MODE == DEC_SKIP && live)
+			sub_start[(size_t)j * P.channels + c] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
 		pump_service(pm, r, L, tid, live, nwords);
 		// ---- subframe header (stream_decoder.c:2450-2518) ----
 		SubHdr h;
@@ -889,6 +942,10 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
 		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
 	} while (0)
+		if (MODE == DEC_SKIP) {
+			decode_samples<0, false, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords);
+			continue;
+		}
 		if (need == 0) DECODE(0);
 		else if (need <= 4) DECODE(4);
 		else if (need <= 8) DECODE(8);
@@ -897,6 +954,24 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		else DECODE(32);
 #undef DECODE
 	}
+	if (MODE == DEC_SKIP) {
+		if (live) {
+			// where the last subframe starts; a frame that went wrong before that is finished here
+			if (br_pos(r) > r.bend)
+				r.err = true;
+			sub_start[(size_t)j * P.channels + P.channels - 1] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
+			if (r.err) {
+				const uint32_t bpos = br_pos(r);
+				const bool past = !endless && ((bpos > r.bend) || ((uint64_t)(bpos >> 3) + 2) * 8 > r.bend);
+				cands[j].end_byte = r.wbase * 4 + (bpos >> 3) + 2;
+				cands[j].status = past ? 4u : 2u;
+				cands[j].reserved = (!past && reserved_code) ? 1u : 0u;
+			}
+		}
+		return;
+	}
+	if (MODE == DEC_SUB && only_c + 1 != P.channels)
+		return;   // (a subframe the walk got through cannot fail here: the same bits, the same checks)
 	if (live) {
 		if (br_pos(r) > r.bend)
 			r.err = true;
@@ -1217,10 +1292,17 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
 }
 
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, hipStream_t st)
+                          int32_t *tmp, uint64_t *sub_start, hipStream_t st)
 {
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
-	hipLaunchKernelGGL(k_dec_frames, dim3(groups), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw);
+	if (sub_start && P.channels >= 2) {
+		hipLaunchKernelGGL(k_dec_frames<DEC_SKIP>, dim3((P.max_frames + P.skip_lw - 1) / P.skip_lw), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands,
+		                   ncand, tmp, P.skip_lw, sub_start);
+		hipLaunchKernelGGL(k_dec_frames<DEC_SUB>, dim3(groups * P.channels), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw,
+		                   sub_start);
+		return;
+	}
+	hipLaunchKernelGGL(k_dec_frames<DEC_WHOLE>, dim3(groups), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw, sub_start);
 }
 
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)

@@ -203,3 +203,51 @@ def test_cooperative_form_decodes_every_golden_stream(monkeypatch):
             dec.close()
         assert (nfr, nwide, bad) == (len(frames), pcm.shape[0], 0), case["name"]
         assert np.array_equal(got, pcm), case["name"]
+
+
+def test_lane_per_frame_form_decodes_every_golden_stream(monkeypatch):
+    """Small batches of streams with two or more channels are decoded in the split form (a walk that finds where every
+    subframe starts, then a lane per subframe), which is what the other tests therefore run; FLAC_AMD_DEC_MODE=lane keeps
+    the lane-per-frame form that large batches use.  It must give back every golden stream exactly as well."""
+    import flac_amd
+    monkeypatch.setenv("FLAC_AMD_DEC_MODE", "lane")
+    for case in CASES:
+        pcm, _meta, frames = golden_util.load_case(case)
+        blob = b"".join(frames)
+        dec = flac_amd.Decoder(case["channels"], case["bps"], blocksize_of(case), device=0, max_input_bytes=len(blob) + 64, max_frames=len(frames) + 8)
+        try:
+            got, nfr, nwide, bad = dec.decode_host(blob, [(0, len(blob), 0, pcm.shape[0])], pcm.shape[0], out_sample_bytes=4)
+        finally:
+            dec.close()
+        assert (nfr, nwide, bad) == (len(frames), pcm.shape[0], 0), case["name"]
+        assert np.array_equal(got, pcm), case["name"]
+
+
+@pytest.mark.parametrize("channels,bps,rate,bs,level", [(2, 16, 44100, 4096, 8), (8, 24, 96000, 1152, 5), (3, 16, 44100, 257, 3)])
+def test_split_and_lane_forms_agree_on_damaged_streams(monkeypatch, channels, bps, rate, bs, level):
+    """The two forms of the frame decoder on streams with every second frame damaged: the same samples, the same
+    number of good and bad frames, and the same per-frame records (status, end of frame), whichever channel's
+    subframe the damage sits in."""
+    import flac_amd
+    nframes = 32
+    pcm, frames = _synthetic_stream(channels, bps, rate, bs, level, nframes, 7 * bs + bps)
+    n = pcm.shape[0]
+    results = {}
+    for mode in ("lane", "split"):
+        monkeypatch.setenv("FLAC_AMD_DEC_MODE", mode)
+        dec = flac_amd.Decoder(channels, bps, bs, device=0, max_input_bytes=sum(map(len, frames)) + 64, max_frames=4 * nframes + 64)
+        try:
+            res = []
+            for seed in range(25):
+                rng = np.random.default_rng(1000 + seed)
+                blob = b"".join(_damage(f, rng) if k % 2 else f for k, f in enumerate(frames))
+                out, nfr, wide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=4)
+                info = dec.frames()
+                res.append((out.copy(), nfr, wide, bad, [(int(r.pos), int(r.status), int(r.end_byte) if r.status in (1, 3) else 0) for r in info]))
+            results[mode] = res
+        finally:
+            dec.close()
+    for seed, (a, b) in enumerate(zip(results["lane"], results["split"])):
+        assert a[1:4] == b[1:4], seed
+        assert np.array_equal(a[0], b[0]), seed
+        assert a[4] == b[4], seed
