@@ -189,9 +189,30 @@ __device__ __forceinline__ void quad_split(uint32_t w, int32_t (&x)[4])
 	x[3] = l - r;
 }
 
+// the sum over the wave, in lane 63: four shifts inside each row of sixteen lanes, then row 0 onto row 1 and
+// rows 0-1 onto rows 2-3 (data-parallel primitives, no LDS crossbar)
+__device__ __forceinline__ uint32_t wave_total32(uint32_t v)
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);    // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);    // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15, rows 1 and 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31, rows 2 and 3
+	return v;
+}
+
+// acc + |a - b| for unsigned a, b
+__device__ __forceinline__ uint32_t sad_acc(uint32_t a, uint32_t b, uint32_t acc)
+{
+	uint32_t r;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+	return r;
+}
+
 // Wave priority: load issue and the reductions ahead of the other workgroups' difference sums (0.130 -> 0.128 ms).
 #define QPRIO(n) __builtin_amdgcn_s_setprio(n)
-__global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_analyze_quad(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
 {
 	const uint32_t f = blockIdx.x, tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
@@ -286,27 +307,39 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 			int32_t raw[4 + FA_CHUNK];
 			load_chunk_lds<4>(raw, (const int32_t *)stage);
 			QPRIO(0);
+			// The errors of the five fixed predictors (fixed.c:240-262) are the absolute values of the signal's
+			// successive differences.  Everything is kept biased by 2^31 (a signed value and its biased form
+			// compare alike as unsigned numbers), so |u - v| of two biased values is one v_sad_u32 that also
+			// adds to the running total: an order costs a subtraction, the bias and the v_sad_u32 per sample.
+			const bool whole = base >= 4 && base + FA_CHUNK <= bsf;   // every sample of the chunk counts (fixed.c:238 starts at the fifth)
+			constexpr uint32_t BIAS = 0x80000000u;
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
-				uint32_t d[4 + FA_CHUNK];
+				// one sample at a time, with the previous value of every order carried along
+				uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
 				for (int k = 0; k < 4 + FA_CHUNK; k++) {
 					int32_t x[4];
 					quad_split((uint32_t)raw[k], x);
-					d[k] = (uint32_t)(x[s] >> wasted[s]);
-				}
-#pragma unroll
-				for (int i = 0; i < FA_CHUNK; i++) {
-					const uint32_t idx = base + i;
-					if (idx >= 4 && idx < bsf) {
-						const uint32_t a = d[4 + i], b = d[3 + i], c = d[2 + i], e = d[1 + i], g = d[i];
-						te[s][0] += abs32((int32_t)a);
-						te[s][1] += abs32((int32_t)(a - b));
-						te[s][2] += abs32((int32_t)(a - 2 * b + c));
-						te[s][3] += abs32((int32_t)(a - 3 * b + 3 * c - e));
-						te[s][4] += abs32((int32_t)(a - 4 * b + 6 * c - 4 * e + g));
+					const uint32_t b0 = (uint32_t)(x[s] >> wasted[s]) ^ BIAS;
+					const uint32_t b1 = (b0 - p0) ^ BIAS, b2 = (b1 - p1) ^ BIAS, b3 = (b2 - p2) ^ BIAS;
+					if (k >= 4) {
+						// (a sample that does not count adds |v - v| = 0)
+						const uint32_t idx = base + (uint32_t)(k - 4);
+						const bool counts = whole || (idx >= 4 && idx < bsf);
+						te[s][0] = sad_acc(b0, counts ? BIAS : b0, te[s][0]);
+						te[s][1] = sad_acc(b0, counts ? p0 : b0, te[s][1]);
+						te[s][2] = sad_acc(b1, counts ? p1 : b1, te[s][2]);
+						te[s][3] = sad_acc(b2, counts ? p2 : b2, te[s][3]);
+						te[s][4] = sad_acc(b3, counts ? p3 : b3, te[s][4]);
 					}
+					p0 = b0;
+					p1 = b1;
+					p2 = b2;
+					p3 = b3;
 				}
+				// (the four signals one after the other: side by side they take twice the registers)
+				asm volatile("" : "+v"(te[s][4]));
 			}
 		}
 	}
@@ -315,8 +348,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze_quad(FaEncParams P, FaBa
 	for (int s = 0; s < 4; s++)
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
-			const uint32_t v = wave_sum32(te[s][k]);
-			if ((tid & 63) == 0)
+			const uint32_t v = wave_total32(te[s][k]);   // in lane 63
+			if ((tid & 63) == 63)
 				sh_te[tid >> 6][s][k] = v;
 		}
 	__syncthreads();
