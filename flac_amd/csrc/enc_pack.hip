@@ -717,10 +717,10 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pack_frame: the same frame (process_frame_, stream_encoder.c:2861) for the common shape - full
-// blocks of 16-bit stereo with mid/side evaluated, at most FA_TILE samples, residuals that need 32-bit
-// sums only, Rice partitions that are whole multiples of a thread's sixteen samples - written so that
-// the frame is passed over once.
+// k_pack_frame: the same frame (process_frame_, stream_encoder.c:2861) for the common shape - blocks
+// of 16-bit stereo with mid/side evaluated, at most FA_TILE samples, residuals that need 32-bit sums
+// only, Rice partitions that are whole multiples of a thread's sixteen samples (a short last block has
+// one partition, stream_encoder.c:2929) - written so that the frame is passed over once.
 //
 // The whole frame's bit stream fits one LDS window, which takes the place of the staged samples once
 // every thread has its own in registers.  Both written subframes are worked out before anything is
@@ -803,8 +803,8 @@ __device__ __forceinline__ uint32_t pq_mask(uint32_t n) { return n >= 32 ? 0xfff
 // itself when verbatim) from the staged stereo words, and the length of its run in bits.  k: the Rice
 // parameter of the partition the samples lie in; pstart: they are its first, so the parameter precedes them.
 template <int HIST>
-__device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHUNK], const PqSub &D, const int32_t *qv, uint32_t base, uint32_t k, bool pstart,
-                                              uint32_t (&uz)[FA_CHUNK])
+__device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHUNK], const PqSub &D, const int32_t *qv, uint32_t base, uint32_t bsf, uint32_t k,
+                                              bool pstart, uint32_t (&uz)[FA_CHUNK])
 {
 	// mid = (L+R)>>1, side = L-R (stream_encoder.c:1991-1992), minus the wasted bits
 	int32_t d[HIST + FA_CHUNK];
@@ -840,7 +840,7 @@ __device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHU
 #pragma unroll
 		for (int i = 0; i < FA_CHUNK; i++)
 			uz[i] = (uint32_t)d[HIST + i] & mask;
-		return FA_CHUNK * D.sbps;
+		return umin32(FA_CHUNK, bsf - base) * D.sbps;
 	}
 	int32_t res[FA_CHUNK];
 	if (D.type == FA_SUB_FIXED)
@@ -849,10 +849,13 @@ __device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHU
 		lpc_residual16_any<HIST, true>(d, qv, D.order, (int)D.shift, 0, res);
 	uint32_t nb = pstart ? D.plen : 0u;
 	const uint32_t k1 = k + 1u;
+	// the frame's first `order` samples are the warm-up, and a short last block ends inside a chunk:
+	// sample idx is coded when order <= idx < bsf, one unsigned comparison
+	const uint32_t from = base - D.order, span = bsf - D.order;
 #pragma unroll
 	for (int i = 0; i < FA_CHUNK; i++) {
 		uz[i] = ((uint32_t)res[i] << 1) ^ (uint32_t)(res[i] >> 31);
-		const bool coded = base + (uint32_t)i >= D.order;   // the frame's first `order` samples are the warm-up
+		const bool coded = from + (uint32_t)i < span;
 		nb += coded ? (uz[i] >> k) + k1 : 0u;
 	}
 	return nb;
@@ -860,14 +863,16 @@ __device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHU
 
 // The thread's run of a subframe into the window from bit p on (FLAC__bitwriter_write_rice_signed_block,
 // bitwriter.c:544; verbatim samples: stream_encoder_framing.c:466).
-__device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint32_t (&uz)[FA_CHUNK], uint32_t base, uint32_t k, bool pstart, uint32_t p)
+__device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint32_t (&uz)[FA_CHUNK], uint32_t base, uint32_t bsf, uint32_t k, bool pstart,
+                                         uint32_t p)
 {
 	if (D.type == FA_SUB_VERBATIM) {
 		const uint32_t lsh = 32u - D.sbps;
 #pragma unroll
 		for (int i = 0; i < FA_CHUNK; i++) {
-			pq_emit(W, p, uz[i] << lsh);
-			p += D.sbps;
+			const bool inside = base + (uint32_t)i < bsf;
+			pq_emit(W, p, inside ? uz[i] << lsh : 0u);
+			p += inside ? D.sbps : 0u;
 		}
 		return;
 	}
@@ -876,9 +881,10 @@ __device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint
 		p += D.plen;
 	}
 	const uint32_t kmask = (1u << k) - 1u, stop = 1u << k, lsh = 31u - k, k1 = k + 1u;
+	const uint32_t from = base - D.order, span = bsf - D.order;
 #pragma unroll
 	for (int i = 0; i < FA_CHUNK; i++) {
-		const bool coded = base + (uint32_t)i >= D.order;
+		const bool coded = from + (uint32_t)i < span;
 		const uint32_t q = p + (uz[i] >> k);
 		const uint32_t vh = ((uz[i] & kmask) | stop) << lsh;
 		pq_emit(W, coded ? q : p, coded ? vh : 0u);
@@ -894,8 +900,8 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 	__shared__ PqShared<HIST> S;
 	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
 	const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t bsf = P.blocksize;   // full frames only
-	const uint64_t frame_start = (uint64_t)f * bsf;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);   // the stream's last block may be short
+	const uint64_t frame_start = (uint64_t)f * P.blocksize;
 	const uint32_t slot_words = P.slot_bytes / 4;
 	uint32_t *slot = slots + (size_t)f * slot_words;
 	constexpr uint32_t HP = ST_HP(HIST);
@@ -942,12 +948,12 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 			S.head[tid] = pre_head;
 			S.stat[tid] = pre_stat;
 		}
-		const uint32_t n0 = HP + bsf;   // (a multiple of 16)
+		const uint32_t n0 = HP + ((bsf + 15) & ~15u);
 #pragma unroll
 		for (uint32_t i = 0; i < NIT; i++) {
 			const uint32_t j = tid + i * FA_THREADS;
 			if (j < n0)
-				S.u.T[j + (j >> 4)] = j >= HP ? (int32_t)pre_w[i] : 0;
+				S.u.T[j + (j >> 4)] = (j >= HP && j - HP < bsf) ? (int32_t)pre_w[i] : 0;
 		}
 	}
 	const uint32_t ca = __builtin_amdgcn_readfirstlane(assign[f]);
@@ -983,7 +989,7 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 				k0 = S.params[sig0][part];
 				ps0 = base == part * D0.psize;
 			}
-			nb0 = pq_values<HIST>(raw, D0, S.q[sig0], base, k0, ps0, uz0);
+			nb0 = pq_values<HIST>(raw, D0, S.q[sig0], base, bsf, k0, ps0, uz0);
 		}
 		if (have && D1.type != FA_SUB_CONSTANT) {
 			if (D1.type != FA_SUB_VERBATIM) {
@@ -991,7 +997,7 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 				k1 = S.params[sig1][part];
 				ps1 = base == part * D1.psize;
 			}
-			nb1 = pq_values<HIST>(raw, D1, S.q[sig1], base, k1, ps1, uz1);
+			nb1 = pq_values<HIST>(raw, D1, S.q[sig1], base, bsf, k1, ps1, uz1);
 		}
 	}
 
@@ -1020,8 +1026,10 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 	const uint32_t nbytes = (bitpos + 7) >> 3;           // zero padding to a whole byte (stream_encoder.c:2885)
 	const uint32_t total_words = (nbytes + 2 + 3) / 4;   // with the CRC-16
 	const uint32_t cap = slot_words < PQ_CAPW ? slot_words : PQ_CAPW;
-	if (total_words + 2 > cap) {
-		// (cannot happen while the slot is sized as slot_bytes_for sizes it; loud if it ever does)
+	const bool ragged = (D0.po && D0.psize % FA_CHUNK) || (D1.po && D1.psize % FA_CHUNK);
+	if (total_words + 2 > cap || ragged) {
+		// (cannot happen: the slot is sized by slot_bytes_for, a full block's partitions are whole chunks by
+		// pack_frame_eligible and a short block has one partition, stream_encoder.c:2929; loud if it ever does)
 		if (tid == 0) {
 			atomicOr(errflag, 1u);
 			frame_bytes[f] = 0;
@@ -1036,9 +1044,9 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 	// ---- everything into the window ----
 	if (have) {
 		if (D0.type != FA_SUB_CONSTANT)
-			pq_codes(W, D0, uz0, base, k0, ps0, pos0 + D0.hbits + off0 + (in0 - nb0));
+			pq_codes(W, D0, uz0, base, bsf, k0, ps0, pos0 + D0.hbits + off0 + (in0 - nb0));
 		if (D1.type != FA_SUB_CONSTANT)
-			pq_codes(W, D1, uz1, base, k1, ps1, pos1 + D1.hbits + off1 + (in1 - nb1));
+			pq_codes(W, D1, uz1, base, bsf, k1, ps1, pos1 + D1.hbits + off1 + (in1 - nb1));
 	}
 	{
 		// subframe headers (stream_encoder_framing.c:366-479): waves 0 and 1 write the warm-up samples and
@@ -1100,7 +1108,7 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 		frame_bytes[f] = nbytes + 2;
 }
 
-// Whether k_pack_frame can write this stream's full frames (the short last one stays with k_pack).
+// Whether k_pack_frame can write this stream's frames.
 static bool pack_frame_eligible(const FaEncParams &P, const FaBatch &B)
 {
 	if (!(B.pairs && P.nsignals == 4 && fa_narrow_only(P)))
@@ -1129,17 +1137,15 @@ void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 	{
 		const char *mode = getenv("FLAC_AMD_PACK");
 		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
-		uint64_t nfull = B.wide_samples / P.blocksize;
-		if (nfull > B.nframes)
-			nfull = B.nframes;
+		const uint32_t nfull = B.nframes;   // (a short last block is one partition: it fits too)
 		if (!generic_only && nfull && pack_frame_eligible(P, B)) {
-			const dim3 grid((uint32_t)nfull);
+			const dim3 grid(nfull);
 			switch (hist) {
 			case 4: hipLaunchKernelGGL(k_pack_frame<4>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
 			case 12: hipLaunchKernelGGL(k_pack_frame<12>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
 			default: hipLaunchKernelGGL(k_pack_frame<32>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
 			}
-			first = (uint32_t)nfull;
+			first = nfull;
 		}
 	}
 	if (first >= B.nframes)
