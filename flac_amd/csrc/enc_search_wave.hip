@@ -262,7 +262,8 @@ struct SwCand {
 #define SW_DOT2 1
 #define SW_REDO 0xffu   // plan type left by the two-taps launch for the one-tap launch to pick up
 
-template <int RES>
+// PAIRS: the samples are 16-bit stereo pairs, one 32-bit word per wide sample (the only layout compiled in then)
+template <int RES, bool PAIRS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaLpcCand *__restrict__ cands,
                    const int32_t *__restrict__ coefs, FaPlan *__restrict__ plans, unsigned long long sig_list, uint32_t nsel)
@@ -313,14 +314,18 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		// lanes along consecutive samples, stored as rows of 64, and sixteen lanes pick up a row each
 		// plus the tail of the row before it ----
 		int32_t d[SW_W];
-		sw_load_run(d, stage, pcm, sig_access(P.channels, B.sample_bytes, B.pairs, s), frame_start, bsf, partial, wasted, ln);
+		SigAccess acc = sig_access(P.channels, B.sample_bytes, B.pairs, s);
+		if (PAIRS)
+			acc.fmt = 0;
+		sw_load_run(d, stage, pcm, acc, frame_start, bsf, partial, wasted, ln);
 		// Which arithmetic the residuals take is decided by what the samples are, not by what they could
 		// be: two taps per v_dot2_i32_i16 when every sample of the frame's signal fits 16 bits (always so
 		// for streams of up to 16 bits, nearly always so for their side signal), a tap per v_mad_i32_i24
 		// otherwise.  Both are exact, so the choice does not show in the result.  Each form is a launch of
 		// its own (the registers of one do not weigh on the other): the two-taps launch comes first and
 		// leaves the subframes it cannot take to the second, which looks at nothing else.
-		int32_t w[SW_W];
+		// (w takes the place of d, last word first, so that the two never exist side by side: 152 registers otherwise)
+		int32_t (&w)[SW_W] = d;
 		if (RES == SW_DOT2) {
 			if (P.bps + ((P.do_ms && s == P.channels + 1) ? 1u : 0u) > 16) {
 				uint32_t mag = 0;
@@ -334,14 +339,10 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 				}
 			}
 			// w[k] holds samples k - 1 and k of the window in its low and high half
-			w[0] = (int32_t)((uint32_t)d[0] << 16);
 #pragma unroll
-			for (int k = 1; k < SW_W; k++)
+			for (int k = SW_W - 1; k >= 1; k--)
 				w[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k], (uint32_t)d[k - 1], 0x05040100u);
-		} else {
-#pragma unroll
-			for (int k = 0; k < SW_W; k++)
-				w[k] = d[k];
+			w[0] = (int32_t)((uint32_t)d[0] << 16);
 		}
 		const uint32_t fold_bps = RES == SW_DOT2 ? umin32(sbps, 16u) : sbps;
 		const uint32_t c31 = 0x80000000u;
@@ -564,7 +565,14 @@ void fa_launch_search_wave(const FaEncParams &P, const FaBatch &B, const void *p
                            hipStream_t st)
 {
 	const dim3 block(64);
-	hipLaunchKernelGGL(k_search_wave<SW_DOT2>, dim3((B.nframes + 7) / 8 * 8 * nsel), block, 0, st, P, B, pcm, stats, cands, coefs, plans, sig_list, nsel);
-	if (nwide)
-		hipLaunchKernelGGL(k_search_wave<SW_TAPS>, dim3((B.nframes + 7) / 8 * 8 * nwide), block, 0, st, P, B, pcm, stats, cands, coefs, plans, wide_list, nwide);
+	const dim3 grid((B.nframes + 7) / 8 * 8 * nsel), gridw((B.nframes + 7) / 8 * 8 * nwide);
+	if (B.pairs) {
+		hipLaunchKernelGGL((k_search_wave<SW_DOT2, true>), grid, block, 0, st, P, B, pcm, stats, cands, coefs, plans, sig_list, nsel);
+		if (nwide)
+			hipLaunchKernelGGL((k_search_wave<SW_TAPS, true>), gridw, block, 0, st, P, B, pcm, stats, cands, coefs, plans, wide_list, nwide);
+	} else {
+		hipLaunchKernelGGL((k_search_wave<SW_DOT2, false>), grid, block, 0, st, P, B, pcm, stats, cands, coefs, plans, sig_list, nsel);
+		if (nwide)
+			hipLaunchKernelGGL((k_search_wave<SW_TAPS, false>), gridw, block, 0, st, P, B, pcm, stats, cands, coefs, plans, wide_list, nwide);
+	}
 }
