@@ -1026,7 +1026,7 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 	const uint32_t nbytes = (bitpos + 7) >> 3;           // zero padding to a whole byte (stream_encoder.c:2885)
 	const uint32_t total_words = (nbytes + 2 + 3) / 4;   // with the CRC-16
 	const uint32_t cap = slot_words < PQ_CAPW ? slot_words : PQ_CAPW;
-	const bool ragged = (D0.po && D0.psize % FA_CHUNK) || (D1.po && D1.psize % FA_CHUNK);
+	const bool ragged = (D0.po && (D0.psize % FA_CHUNK || D0.psize == 0)) || (D1.po && (D1.psize % FA_CHUNK || D1.psize == 0));
 	if (total_words + 2 > cap || ragged) {
 		// (cannot happen: the slot is sized by slot_bytes_for, a full block's partitions are whole chunks by
 		// pack_frame_eligible and a short block has one partition, stream_encoder.c:2929; loud if it ever does)

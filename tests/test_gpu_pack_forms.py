@@ -30,6 +30,8 @@ SETTINGS = [
     ("level8_prec12", 8, {"qlp_coeff_precision": 12}),
     ("level8_noverbatim", 8, {"disable_verbatim_subframes": 1}),
     ("level8_noconstant", 8, {"disable_constant_subframes": 1}),
+    ("order32_prec10", 8, {"max_lpc_order": 32, "qlp_coeff_precision": 10}),   # the 32-sample history class of both forms
+    ("order20_prec9_po4", 8, {"max_lpc_order": 20, "qlp_coeff_precision": 9, "max_residual_partition_order": 4}),
 ]
 
 
