@@ -167,25 +167,39 @@ def main():
     out_dev = torch.empty(out_cap, dtype=torch.uint8, device=dev)
     fbytes_dev = torch.zeros(nframes, dtype=torch.int32, device=dev)
     offs_dev = torch.zeros(nframes + 1, dtype=torch.int64, device=dev)
-    totals = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+    # the exchange runs beside the next step's kernels (nothing on the device waits for the offsets: they are
+    # needed when the shards are written out), so its buffers rotate: step k uses pair k & 1, whose previous
+    # use, two steps back, is waited for first
+    totals = [torch.zeros(world, dtype=torch.int64, device=coll_dev) for _ in range(2)]
+    mine = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(2)]
+    pending = []
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
+    def step(k):
         enc.encode_device(pcm_dev.data_ptr(), 2, wide, out_dev.data_ptr(), out_cap, fbytes_dev.data_ptr(),
                           offs_dev.data_ptr(), first_frame=first_frame, is_last=is_last, stream=stream)
         if world > 1:
             # stream offsets of the shards: all-gather of the per-rank byte totals over RCCL
-            dist.all_gather_into_tensor(totals, offs_dev[nframes:nframes + 1].to(coll_dev))
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            mine[k & 1].copy_(offs_dev[nframes:nframes + 1], non_blocking=True)
+            pending.append(dist.all_gather_into_tensor(totals[k & 1], mine[k & 1], async_op=True))
 
-    for _ in range(args.warmup):
-        step()
+    def drain():
+        while pending:
+            pending.pop(0).wait()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
