@@ -118,27 +118,33 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	// the batch leaves the chip room, frames with two or more channels are decoded in the split form, a walk that
 	// finds where every subframe starts and then a lane per subframe (FLAC_AMD_DEC_MODE=lane keeps a lane per frame,
 	// =split forces the split form, for comparisons).  The walk costs about half of what decoding the same samples
-	// costs, so a batch large enough to fill the chip with whole frames is better off without it: measured
-	// (tools/dec_mode_probe.py), the split form wins up to about 24 000 subframes (16-bit stereo: 1.56 -> 1.20 ms for
-	// 6 460 frames; eight channels of 24 bits: 6.6 -> 4.4 ms for 2 813 frames) and loses beyond (16 384 stereo
-	// frames: 1.71 -> 1.91 ms).
+	// costs, so a batch large enough to fill the chip with whole frames is better off without it.  Measured
+	// (tools/dec_mode_probe.py, tools/bench_configs.py; frames stage, a lane per frame -> split): 16-bit stereo
+	// 256 frames 1.31 -> 1.01 ms, 6 460 frames 1.49 -> 1.20, 16 384 frames 1.61 -> 1.39; 24-bit stereo 14 063 frames
+	// 1.78 -> 1.46; eight channels of 24 bits 2 813 frames 5.9 -> 3.9; 67 500 stereo frames (135 000 subframes)
+	// 3.70 (32 frames per wave) -> 4.39.  Eight frames per wave up to 10 000 subframes, sixteen beyond.
 	{
 		const char *mode = getenv("FLAC_AMD_DEC_MODE");
 		const uint64_t units = (uint64_t)max_frames * channels;
-		d->split = channels >= 2 && units <= 24000 && !(mode && (!strcmp(mode, "lane") || !strcmp(mode, "coop")));
+		d->split = channels >= 2 && units <= 40000 && !(mode && (!strcmp(mode, "lane") || !strcmp(mode, "coop")));
 		if (mode && !strcmp(mode, "split") && channels >= 2)
 			d->split = 1;
 		uint32_t lw = 4;
 		if (d->split)
-			lw = units <= 8 * 3000 ? 8 : 16;
-		else
+			lw = units <= 10000 ? 8 : 16;
+		else {
 			while (lw < 16 && (max_frames + lw - 1) / lw > 2048)
 				lw *= 2;
+			// beyond what the chip holds at once at sixteen frames per wave, thirty-two: half the waves, each as long
+			// (C5: frames stage 4.52 -> 3.70 ms)
+			if ((max_frames + 15) / 16 > 3000)
+				lw = 32;
+		}
 		if (d->split)
 			ALLOC(d->sub_start, sizeof(uint64_t) * (size_t)max_frames * channels);
 		if (const char *env = getenv("FLAC_AMD_DEC_LW")) {
 			const uint32_t v = (uint32_t)atoi(env);
-			if (v >= 1 && v <= 16 && (v & (v - 1)) == 0)
+			if (v >= 1 && v <= (d->split ? 16u : 32u) && (v & (v - 1)) == 0)
 				lw = v;
 		}
 		d->lw = lw;

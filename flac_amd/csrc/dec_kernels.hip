@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint
 // samples, long before that lane gets there.  A lane that outruns its ring (a very long unary run)
 // reads global memory itself.
 // ---------------------------------------------------------------------------------------------
-#define DEC_MAXLW 16        // frames per wave at most
+#define DEC_MAXLW 16        // frames per wave at most, except for the largest batches (k_dec_frames<.., 32>)
 #define RING_CHUNK 64       // words per refill (one per lane of the wave)
 #define RING_WORDS 128      // words per lane in LDS: two chunks
 #define DEC_BLOCK 16        // samples decoded between refill / flush points
@@ -502,19 +502,24 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 // ---------------------------------------------------------------------------------------------
 // k_dec_frames
 // ---------------------------------------------------------------------------------------------
+// MAXLW: the most frames a wave of this instance carries (the LDS it takes grows with it)
+template <int MAXLW>
 struct DecLds {
-	int32_t q[FA_MAX_ORDER][DEC_MAXLW];          // predictor coefficients per lane
-	int32_t w[FA_MAX_ORDER][DEC_MAXLW];          // warm-up samples per lane
-	uint32_t ring[DEC_MAXLW][RING_WORDS];        // input words per lane
-	int32_t out[2 * DEC_BLOCK * DEC_MAXLW];      // a block of decoded samples, [sample][lane]; second half: spare
+	static constexpr int maxlw = MAXLW;
+	int32_t q[FA_MAX_ORDER][MAXLW];          // predictor coefficients per lane
+	int32_t w[FA_MAX_ORDER][MAXLW];          // warm-up samples per lane
+	uint32_t ring[MAXLW][RING_WORDS];        // input words per lane
+	int32_t out[2 * DEC_BLOCK * MAXLW];      // a block of decoded samples, [sample][lane]; second half: spare
 };
 
-// The wave-level input pump.  Up to two refills are in flight (one word per thread each); they are
-// put into the rings at the next service point, a block of samples later.
+// The wave-level input pump.  Up to four refills are in flight (one word per thread each); they are
+// put into the rings at the next service point, a block of samples later.  (Four, because two cannot feed
+// sixteen lanes of 24-bit frames, 7.5 words per lane and block: 2.94 -> 1.96 ms for 14 063 such frames.)
+#define PUMP_SLOTS 4
 struct Pump {
-	uint32_t data[2];
-	int lane[2];      // whose ring the word goes to, -1 = slot free
-	uint32_t half[2]; // which half of that ring
+	uint32_t data[PUMP_SLOTS];
+	int lane[PUMP_SLOTS];      // whose ring the word goes to, -1 = slot free
+	uint32_t half[PUMP_SLOTS]; // which half of that ring
 };
 
 // what a lane knows about its current subframe once the subframe header is parsed
@@ -531,10 +536,12 @@ __device__ __forceinline__ uint32_t wave_value(uint32_t v, int lane_id) { return
 
 // Service point (every lane of the wave takes part): land the refills in flight, then start
 // refills for up to two lanes that have moved into the newest chunk of their ring.
-__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint32_t tid, bool live, uint64_t nwords)
+template <typename LDS>
+__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_t tid, bool live, uint64_t nwords)
 {
+	constexpr int NSL = PUMP_SLOTS;
 #pragma unroll
-	for (int sl = 0; sl < 2; sl++) {
+	for (int sl = 0; sl < NSL; sl++) {
 		if (pm.lane[sl] >= 0) {
 			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = __builtin_bswap32(pm.data[sl]);
 			if ((int)tid == pm.lane[sl])
@@ -546,7 +553,7 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 	const bool want = live && !r.err && r.wrel + RING_CHUNK >= r.limit && r.limit < r.nrel;
 	uint64_t m = __ballot(want);
 #pragma unroll
-	for (int sl = 0; sl < 2; sl++) {
+	for (int sl = 0; sl < NSL; sl++) {
 		if (m) {
 			const int ln = __ffsll((unsigned long long)m) - 1;
 			m &= m - 1;
@@ -580,14 +587,14 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, DecLds &L, uint
 // at a time in LDS and written to plane[sample * LW + lane] by all threads together.
 // SKIP: the subframe is only walked through, to find where it ends: symbols are measured, not turned into
 // values, nothing is predicted or stored (M is 0).
-template <int M, bool WIDE, bool MUL24, bool SKIP = false>
-__device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, DecLds &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
+template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS>
+__device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
                                                uint32_t bsf, bool live, uint64_t nwords)
 {
 	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
 	// are switched on at the first residual; lanes without a predictor keep zeros
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
-	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
+	const uint32_t lane = tid < (uint32_t)LDS::maxlw ? tid : 0;
 #pragma unroll
 	for (int j = 0; j < M; j++) {
 		q[j] = 0;
@@ -603,7 +610,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
 	// lanes that carry no frame write their block samples to a spare area
-	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * DEC_MAXLW];
+	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * LDS::maxlw];
 	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
 		pump_service(pm, r, L, tid, live, nwords);
 		if (br_pos(r) > r.bend) {
@@ -765,11 +772,11 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 #define DEC_SUB 2
 #define DEC_NO_START 0xffffffffffffffffull
 
-template <int MODE>
+template <int MODE, int MAXLW>
 __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
                                                           FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start)
 {
-	__shared__ DecLds L;
+	__shared__ DecLds<MAXLW> L;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ncand = ncand_ptr[0];
 	const uint32_t grp = MODE == DEC_SUB ? blockIdx.x / P.channels : blockIdx.x;
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		return;
 	const uint32_t j = grp * LW + tid;
 	bool live = tid < LW && j < ncand;
-	const uint32_t lane = tid < DEC_MAXLW ? tid : 0;
+	const uint32_t lane = tid < (uint32_t)MAXLW ? tid : 0;
 	FaFrameCand cd;
 	if (live)
 		cd = cands[j];
@@ -814,9 +821,9 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	r.ring = L.ring[lane];
 	// the first two chunks of every frame, all requested before the first is waited for
 	{
-		uint32_t first[2 * DEC_MAXLW];
+		uint32_t first[2 * MAXLW];
 #pragma unroll
-		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
+		for (uint32_t ln = 0; ln < (uint32_t)MAXLW; ln++) {
 			const uint64_t wb = ((uint64_t)wave_value((uint32_t)(r.wbase >> 32), (int)ln) << 32) | wave_value((uint32_t)r.wbase, (int)ln);
 #pragma unroll
 			for (uint32_t c = 0; c < 2; c++) {
@@ -825,16 +832,18 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 			}
 		}
 #pragma unroll
-		for (uint32_t ln = 0; ln < DEC_MAXLW; ln++) {
+		for (uint32_t ln = 0; ln < (uint32_t)MAXLW; ln++) {
 			L.ring[ln][tid] = __builtin_bswap32(first[2 * ln]);
 			L.ring[ln][RING_CHUNK + tid] = __builtin_bswap32(first[2 * ln + 1]);
 		}
 		r.limit = 2 * RING_CHUNK;
 	}
 	Pump pm;
-	pm.lane[0] = pm.lane[1] = -1;
-	pm.data[0] = pm.data[1] = 0;
-	pm.half[0] = pm.half[1] = 0;
+	for (int sl = 0; sl < PUMP_SLOTS; sl++) {
+		pm.lane[sl] = -1;
+		pm.data[sl] = 0;
+		pm.half[sl] = 0;
+	}
 	br_start(r, (uint32_t)(start_bit - r.wbase * 32));
 	const uint32_t bsf = cd.blocksize;
 	uint32_t bs_w = bsf;
@@ -1295,14 +1304,18 @@ void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStr
                           int32_t *tmp, uint64_t *sub_start, hipStream_t st)
 {
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
-	if (sub_start && P.channels >= 2) {
-		hipLaunchKernelGGL(k_dec_frames<DEC_SKIP>, dim3((P.max_frames + P.skip_lw - 1) / P.skip_lw), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands,
-		                   ncand, tmp, P.skip_lw, sub_start);
-		hipLaunchKernelGGL(k_dec_frames<DEC_SUB>, dim3(groups * P.channels), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw,
-		                   sub_start);
+	const uint32_t *words = (const uint32_t *)flac;
+	if (sub_start && P.channels >= 2 && P.lw <= 16 && P.skip_lw <= 16) {
+		hipLaunchKernelGGL((k_dec_frames<DEC_SKIP, 16>), dim3((P.max_frames + P.skip_lw - 1) / P.skip_lw), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand,
+		                   tmp, P.skip_lw, sub_start);
+		hipLaunchKernelGGL((k_dec_frames<DEC_SUB, 16>), dim3(groups * P.channels), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, P.lw, sub_start);
 		return;
 	}
-	hipLaunchKernelGGL(k_dec_frames<DEC_WHOLE>, dim3(groups), dim3(DEC_LANES), 0, st, P, (const uint32_t *)flac, streams, cands, ncand, tmp, P.lw, sub_start);
+	// a lane per frame; the largest batches put 32 frames into a wave (twice the LDS, half the waves)
+	if (P.lw <= 16)
+		hipLaunchKernelGGL((k_dec_frames<DEC_WHOLE, 16>), dim3(groups), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, P.lw, sub_start);
+	else
+		hipLaunchKernelGGL((k_dec_frames<DEC_WHOLE, 32>), dim3(groups), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, P.lw, sub_start);
 }
 
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)

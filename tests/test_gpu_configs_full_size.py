@@ -184,11 +184,12 @@ def test_batch_decode_one_gpus_share_of_ten_thousand_streams():
         assert bool((got[idx] == sources[which].unsqueeze(0)).all()), "copies of stream %d" % which
 
 
-@pytest.mark.parametrize("lw", [4, 8, 16])
-def test_decoder_frames_per_wave(lw, monkeypatch):
-    """The decoder carries 4, 8 or 16 frames per wave depending on the batch; every choice must
-    decode every golden stream exactly."""
+@pytest.mark.parametrize("mode,lw", [("split", 4), ("split", 8), ("split", 16), ("lane", 4), ("lane", 8), ("lane", 16), ("lane", 32)])
+def test_decoder_frames_per_wave(mode, lw, monkeypatch):
+    """The decoder carries 4 to 32 frames per wave (32 only with a lane per frame, for the largest batches) depending
+    on the batch; every choice, in either form, must decode every golden stream exactly."""
     import flac_amd
+    monkeypatch.setenv("FLAC_AMD_DEC_MODE", mode)
     monkeypatch.setenv("FLAC_AMD_DEC_LW", str(lw))
     for case in golden_util.load_index():
         pcm, _meta, frames = golden_util.load_case(case)
