@@ -1,0 +1,641 @@
+// The frame decoder proper (k_dec_frames and everything under it), as a header: each instance of the kernel
+// is compiled in a translation unit of its own (dec_frames_*.hip), side by side, because one instance
+// takes minutes to compile (every predictor-order class, three arithmetic variants, sixteen samples unrolled).
+#ifndef FLAC_AMD_DEC_FRAMES_H
+#define FLAC_AMD_DEC_FRAMES_H
+
+#include <hip/hip_runtime.h>
+
+#include "dec_kernels.h"
+
+#define DEC_LANES 64
+
+__device__ __forceinline__ uint32_t d_ilog2(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+
+// the fixed predictors as filter coefficients (fixed.c:395)
+__constant__ static const int8_t c_fixed_q[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
+
+// ---------------------------------------------------------------------------------------------
+// bit reader (bitreader.c): MSB-first bits out of big-endian 32-bit words.
+//
+// A lane keeps two consecutive words of its frame in registers and counts the unread bits of the
+// first (0..31); the next 32 bits of the stream are one v_alignbit_b32 of the pair, and moving on
+// by up to 32 bits is a subtraction plus, when a word boundary is crossed, a step to the next word:
+// no 64-bit shifts.  Words come from a per-lane ring in LDS that the whole wave refills together: 64
+// lanes fetch 64 consecutive words of ONE lane's frame in a single coalesced load, between blocks of
+// samples, long before that lane gets there.  A lane that outruns its ring (a very long unary run)
+// reads global memory itself.
+// ---------------------------------------------------------------------------------------------
+#define DEC_MAXLW 16        // frames per wave at most, except for the largest batches (k_dec_frames<.., 32>)
+#define RING_CHUNK 64       // words per refill (one per lane of the wave)
+#define RING_WORDS 128      // words per lane in LDS: two chunks
+#define DEC_BLOCK 16        // samples decoded between refill / flush points
+
+struct BitRd {
+	const uint32_t *wg;  // the frame's first word in global memory (word index wbase of the input)
+	uint64_t wbase;      // index of that word in the input
+	uint32_t cur;        // the word being read: its last `rem` bits are unread
+	uint32_t nxt;        // the word after it, all unread (both already byte-swapped)
+	uint32_t rem;        // 0..31
+	uint32_t wrel;       // index, relative to wbase, of the word after nxt
+	uint32_t nrel;       // words from wbase to the end of the input (saturated)
+	uint32_t limit;      // words [0, limit) have been in the ring; the last RING_WORDS of them still are
+	uint32_t bend;       // first bit past the stream on the same scale (saturated)
+	const uint32_t *ring;  // this lane's RING_WORDS words of LDS
+	bool err;
+};
+
+// Bits consumed, counted from the start of word wbase: cur and nxt are words wrel-2 and wrel-1 of the frame, of which
+// rem + 32 bits are still unread.
+__device__ __forceinline__ uint32_t br_pos(const BitRd &r) { return 32u * (r.wrel - 1u) - r.rem; }
+
+// The refill protocol keeps limit - RING_WORDS <= wrel, so one compare tells whether the ring has
+// the word; a lane that has outrun its ring reads global memory itself.
+__device__ __forceinline__ uint32_t br_fetch(BitRd &r)
+{
+	uint32_t v;
+	if (r.wrel < r.limit)
+		v = r.ring[r.wrel & (RING_WORDS - 1)];   // the ring holds the words already byte-swapped
+	else
+		v = __builtin_bswap32(r.wrel < r.nrel ? r.wg[r.wrel] : 0u);
+	r.wrel++;
+	return v;
+}
+
+// start reading at bit sbit (< 32 * RING_CHUNK - 96) of the frame's first chunk
+__device__ __forceinline__ void br_start(BitRd &r, uint32_t sbit)
+{
+	r.err = false;
+	const uint32_t i = sbit >> 5, s = sbit & 31;
+	// a position on a word boundary is "nothing left of the word before"
+	r.cur = s ? r.ring[i] : 0u;
+	r.nxt = r.ring[s ? i + 1 : i];
+	r.rem = (32u - s) & 31u;
+	r.wrel = s ? i + 2 : i + 1;
+}
+
+// the next 32 bits: the last rem bits of cur, then the first 32 - rem of nxt (one v_alignbit_b32)
+__device__ __forceinline__ uint32_t br_peek(const BitRd &r) { return __builtin_amdgcn_alignbit(r.cur, r.nxt, r.rem); }
+
+// n <= 32
+__device__ __forceinline__ void br_drop(BitRd &r, uint32_t n)
+{
+	const int32_t left = (int32_t)r.rem - (int32_t)n;
+	if (left < 0) {
+		r.cur = r.nxt;
+		r.nxt = br_fetch(r);
+	}
+	r.rem = (uint32_t)left & 31u;
+}
+
+// n <= 32
+__device__ __forceinline__ uint32_t br_get(BitRd &r, uint32_t n)
+{
+	if (n == 0)
+		return 0;
+	const uint32_t v = br_peek(r) >> (32 - n);
+	br_drop(r, n);
+	return v;
+}
+
+__device__ __forceinline__ int32_t br_get_signed(BitRd &r, uint32_t n)
+{
+	if (n == 0)
+		return 0;
+	const uint32_t v = br_get(r, n);
+	return (int32_t)(v << (32 - n)) >> (32 - n);
+}
+
+// FLAC__bitreader_read_unary_unsigned (bitreader.c:666): zero bits before the next one bit
+__device__ __forceinline__ uint32_t br_unary(BitRd &r)
+{
+	uint32_t n = 0;
+	for (;;) {
+		const uint32_t hi = br_peek(r);
+		if (hi) {
+			const uint32_t z = (uint32_t)__clz((int)hi);
+			br_drop(r, z + 1);
+			return n + z;
+		}
+		n += 32;
+		br_drop(r, 32);
+		if (br_pos(r) > r.bend) {
+			r.err = true;
+			return n;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dec_frames
+// ---------------------------------------------------------------------------------------------
+// MAXLW: the most frames a wave of this instance carries (the LDS it takes grows with it)
+template <int MAXLW>
+struct DecLds {
+	static constexpr int maxlw = MAXLW;
+	int32_t q[FA_MAX_ORDER][MAXLW];          // predictor coefficients per lane
+	int32_t w[FA_MAX_ORDER][MAXLW];          // warm-up samples per lane
+	uint32_t ring[MAXLW][RING_WORDS];        // input words per lane
+	int32_t out[2 * DEC_BLOCK * MAXLW];      // a block of decoded samples, [sample][lane]; second half: spare
+};
+
+// The wave-level input pump.  Up to four refills are in flight (one word per thread each); they are
+// put into the rings at the next service point, a block of samples later.  (Four, because two cannot feed
+// sixteen lanes of 24-bit frames, 7.5 words per lane and block: 2.94 -> 1.96 ms for 14 063 such frames.)
+#define PUMP_SLOTS 4
+struct Pump {
+	uint32_t data[PUMP_SLOTS];
+	int lane[PUMP_SLOTS];      // whose ring the word goes to, -1 = slot free
+	uint32_t half[PUMP_SLOTS]; // which half of that ring
+};
+
+// what a lane knows about its current subframe once the subframe header is parsed
+struct SubHdr {
+	uint32_t kind;      // 0 constant, 1 verbatim, 2 fixed, 3 lpc
+	uint32_t order, wasted, sbps;
+	uint32_t po, plen, pesc, psize;
+	int shift;
+	bool lane_wide;
+	int32_t constant;
+};
+
+__device__ __forceinline__ uint32_t wave_value(uint32_t v, int lane_id) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_id); }
+
+// Service point (every lane of the wave takes part): land the refills in flight, then start
+// refills for up to two lanes that have moved into the newest chunk of their ring.
+template <typename LDS>
+__device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_t tid, bool live, uint64_t nwords)
+{
+	constexpr int NSL = PUMP_SLOTS;
+#pragma unroll
+	for (int sl = 0; sl < NSL; sl++) {
+		if (pm.lane[sl] >= 0) {
+			L.ring[pm.lane[sl]][pm.half[sl] * RING_CHUNK + tid] = __builtin_bswap32(pm.data[sl]);
+			if ((int)tid == pm.lane[sl])
+				r.limit += RING_CHUNK;
+			pm.lane[sl] = -1;
+		}
+	}
+	// a lane wants the next chunk once its read position is inside the newest one
+	const bool want = live && !r.err && r.wrel + RING_CHUNK >= r.limit && r.limit < r.nrel;
+	uint64_t m = __ballot(want);
+#pragma unroll
+	for (int sl = 0; sl < NSL; sl++) {
+		if (m) {
+			const int ln = __ffsll((unsigned long long)m) - 1;
+			m &= m - 1;
+			const uint32_t lim = wave_value(r.limit, ln);
+			const uint64_t wb = ((uint64_t)wave_value((uint32_t)(r.wbase >> 32), ln) << 32) | wave_value((uint32_t)r.wbase, ln);
+			const uint64_t at = wb + lim + tid;
+			pm.data[sl] = at < nwords ? (r.wg - r.wbase)[at] : 0u;
+			pm.lane[sl] = ln;
+			pm.half[sl] = (lim / RING_CHUNK) & 1;
+		}
+	}
+}
+
+// The samples of one subframe for every lane of the wave: verbatim words, or Rice-coded residuals
+// (stream_decoder.c:2692,2715) turned into samples on the spot by the predictor recurrence
+// (FLAC__fixed_restore_signal, fixed.c:395; FLAC__lpc_restore_signal[_wide], lpc.c:795,1061; a
+// fixed predictor is the LPC filter {1}, {2,-1}, {3,-3,1}, {4,-6,4,-1} with shift 0 in wrapping
+// 32-bit arithmetic).  M bounds the predictor orders present in the wave.
+//
+// The common case runs without control flow: every lane cuts a Rice symbol out of the next 32 bits
+// (one count of leading zeros, a saturating add, one bit-field extract), predicts, shifts its history
+// and, if the symbol ended in the next word, steps on with the ring word requested at the start of the
+// sample.  Lanes for which that is not the right
+// thing at this sample (warm-up and verbatim samples, a partition boundary, an escaped partition,
+// a symbol longer than 32 bits, a ring that has fallen behind) throw the result away and take
+// the one divergent region, which uses the general bit reader.  Because the prediction and the
+// history shift run for all lanes on every sample, the history is renamed across the unrolled
+// samples rather than moved.
+//
+// Samples, shifted back up by the wasted bits (stream_decoder.c:2511-2515), are collected a block
+// at a time in LDS and written to plane[sample * LW + lane] by all threads together.
+// SKIP: the subframe is only walked through, to find where it ends: symbols are measured, not turned into
+// values, nothing is predicted or stored (M is 0).
+template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS>
+__device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
+                                               uint32_t bsf, bool live, uint64_t nwords)
+{
+	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
+	// are switched on at the first residual; lanes without a predictor keep zeros
+	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
+	const uint32_t lane = tid < (uint32_t)LDS::maxlw ? tid : 0;
+#pragma unroll
+	for (int j = 0; j < M; j++) {
+		q[j] = 0;
+		hist[j] = 0;
+	}
+	uint32_t next_part = h.order;  // sample index where the next partition parameter is read
+	uint32_t part_end = 0;         // end of the partition whose parameter was read last
+	uint32_t k = 0, kp1 = 1, raw_bits = 0;
+	bool escape = false;
+	// samples below seg_end are plain Rice symbols with parameter k; fast_end is seg_end while
+	// the ring is sure to hold every word the rest of the block can ask for, else 0
+	uint32_t seg_end = 0, fast_end = 0;
+	// samples below work_end need parsing; a constant subframe needs none
+	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
+	// lanes that carry no frame write their block samples to a spare area
+	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * LDS::maxlw];
+	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
+		pump_service(pm, r, L, tid, live, nwords);
+		if (br_pos(r) > r.bend) {
+			r.err = true;
+			work_end = 0;
+			seg_end = 0;
+		}
+		// the fast path takes at most one word per sample
+		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
+		// SKIP: a sample is half a dozen instructions, fewer cycles than an LDS read takes, so the ring is read two
+		// words ahead of the pair in use: n2 and n3 are the words after nxt, n3 requested a step before it can be
+		// needed (garbage while the ring has not got that far, which is when fast_end is 0 and nothing uses them)
+		uint32_t n2 = 0, n3 = 0;
+		if (SKIP) {
+			n2 = r.ring[r.wrel & (RING_WORDS - 1)];
+			n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+		}
+		// unrolled in full: the history needs no moves at all, and the compiler schedules across samples
+		// (unrolled by four: 1.70 ms for the benchmark's frames, in full: 1.63)
+#pragma unroll
+		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+			const uint32_t i = i0 + s;
+			// the word a step into the next word at the end of this sample would bring in
+			const uint32_t ring_word = SKIP ? n2 : r.ring[r.wrel & (RING_WORDS - 1)];
+			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the next 32 bits: count of
+			// leading zeros (all ones for "none of the 32 is set": the saturating add then fails the length test),
+			// stop bit, k low bits
+			const uint32_t win = br_peek(r);
+			uint32_t z, total;
+			asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
+			asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
+			const bool fast = i < fast_end && total <= 32;
+			const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
+			const uint32_t uf = (z << k) | lsbs;
+			int32_t res = fast ? (int32_t)((uf >> 1) ^ (0u - (uf & 1))) : h.constant;
+			const uint32_t used = fast ? total : 0;
+			{
+				// at most one word boundary is crossed (used <= 32)
+				const int32_t left = (int32_t)r.rem - (int32_t)used;
+				const bool cross = left < 0;
+				r.cur = cross ? r.nxt : r.cur;
+				r.nxt = cross ? ring_word : r.nxt;
+				r.wrel += cross ? 1u : 0u;
+				r.rem = (uint32_t)left & 31u;
+				if (SKIP) {
+					n2 = cross ? n3 : n2;
+					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+				}
+			}
+			if (!fast && i < work_end) {
+				if (h.kind >= 2) {
+					if (i < h.order)
+						res = L.w[i][lane];
+					else {
+						if (i == next_part) {
+							if (M > 0 && i == h.order) {
+#pragma unroll
+								for (int j = 0; j < M; j++)
+									q[j] = (uint32_t)j < h.order ? L.q[j][lane] : 0;
+							}
+							// a first partition as long as the warm-up holds no residual but still has its
+							// parameter in the stream (stream_decoder.c:2734 lets it through, :2747-2767
+							// reads it): its successor's parameter follows at once
+							do {
+								k = br_get(r, h.plen);
+								escape = k >= h.pesc;
+								if (escape) {
+									raw_bits = br_get(r, 5);
+									k = 0;
+								}
+								part_end = h.po > 0 ? part_end + h.psize : bsf;
+							} while (part_end <= i && !r.err && br_pos(r) <= r.bend);
+							kp1 = k + 1;
+							next_part = part_end;
+							seg_end = escape ? 0 : next_part;
+						}
+						if (!escape) {
+							const uint32_t msbs = br_unary(r);
+							const uint32_t low = br_get(r, k);
+							const uint32_t u = (msbs << k) | low;
+							res = (int32_t)(u >> 1) ^ -(int32_t)(u & 1);
+						} else
+							res = br_get_signed(r, raw_bits);
+					}
+				} else
+					res = br_get_signed(r, h.sbps);
+				if (r.err) {
+					work_end = 0;
+					seg_end = 0;
+				}
+				fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
+				if (SKIP) {
+					n2 = r.ring[r.wrel & (RING_WORDS - 1)];
+					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+				}
+			}
+			int32_t v = res;
+			if (M > 0) {
+				int32_t pred;
+				if (WIDE) {
+					int64_t sum = 0;
+#pragma unroll
+					for (int j = 0; j < M; j++)
+						sum += (int64_t)q[j] * (int64_t)hist[j];
+					pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
+				} else {
+					int32_t sum = 0;
+					if (MUL24) {
+						// two chains of 24-bit multiply-adds, one instruction per tap
+						int32_t s0, s1 = 0;
+						asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(hist[0]));
+						if (M > 1)
+							asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(hist[1]));
+#pragma unroll
+						for (int j = 2; j < M; j += 2) {
+							asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(q[j]), "v"(hist[j]), "v"(s0));
+							if (j + 1 < M)
+								asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(q[j + 1]), "v"(hist[j + 1]), "v"(s1));
+						}
+						sum = s0 + s1;
+					} else {
+#pragma unroll
+						for (int j = 0; j < M; j++)
+							sum += q[j] * hist[j];
+					}
+					pred = sum >> h.shift;
+				}
+				v = (int32_t)((uint32_t)res + (uint32_t)pred);
+#pragma unroll
+				for (int j = M - 1; j > 0; j--)
+					hist[j] = hist[j - 1];
+				hist[0] = v;
+			}
+			if (!SKIP)
+				slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
+		}
+		if (!SKIP) {
+			// the block goes out with all 64 threads along memory order
+			const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
+			for (uint32_t e = tid; e < nblk; e += DEC_LANES)
+				plane[(size_t)i0 * LW + e] = L.out[e];
+		}
+	}
+}
+
+// One lane per frame; a wave carries LW <= 16 frames in its first lanes, the other lanes only help
+// moving data.  A wave's pace is set by its longest dependent chain, not by how many of its lanes
+// decode, so a batch is spread over as many waves as the chip can run at once.
+//
+// The chain is a frame's samples one after the other, and a subframe can only be started where the one
+// before it ends.  For batches that leave the chip room, the chain is cut: DEC_SKIP walks the subframes
+// of every channel but the last without decoding them (a symbol's length is all it takes: a quarter of
+// the instructions) and leaves the bit position at which each subframe starts; DEC_SUB then runs one lane
+// per (frame, channel), a wave taking one channel of LW frames, so the longest chain is one subframe.
+// A frame the walk found malformed gets its status there and is left alone by DEC_SUB; the lane of the
+// last channel finishes the frame (padding, end, status) as the single pass does.
+#define DEC_WHOLE 0
+#define DEC_SKIP 1
+#define DEC_SUB 2
+#define DEC_NO_START 0xffffffffffffffffull
+
+template <int MODE, int MAXLW>
+__global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
+                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start)
+{
+	__shared__ DecLds<MAXLW> L;
+	const uint32_t tid = threadIdx.x;
+	const uint32_t ncand = ncand_ptr[0];
+	const uint32_t grp = MODE == DEC_SUB ? blockIdx.x / P.channels : blockIdx.x;
+	const uint32_t only_c = MODE == DEC_SUB ? blockIdx.x % P.channels : 0;
+	if (grp * LW >= ncand)
+		return;
+	const uint32_t j = grp * LW + tid;
+	bool live = tid < LW && j < ncand;
+	const uint32_t lane = tid < (uint32_t)MAXLW ? tid : 0;
+	FaFrameCand cd;
+	if (live)
+		cd = cands[j];
+	else {
+		cd.pos = 0; cd.sample = 0; cd.hdr_bytes = 0; cd.blocksize = 0; cd.assignment = 0; cd.stream = 0; cd.status = 0; cd.end_byte = 0;
+	}
+	// where the lane starts reading, in bits from the start of the input
+	uint64_t start_bit = (cd.pos + cd.hdr_bytes) * 8;
+	if (MODE == DEC_SUB) {
+		if (live) {
+			start_bit = sub_start[(size_t)j * P.channels + only_c];
+			if (start_bit == DEC_NO_START) {
+				live = false;
+				start_bit = 0;
+			}
+		} else
+			start_bit = 0;
+	}
+	const uint64_t nwords = (P.flac_bytes + 3) / 4;
+	BitRd r;
+	r.wbase = MODE == DEC_SUB ? start_bit >> 5 : cd.pos >> 2;
+	r.wg = flac_words + r.wbase;
+	r.nrel = nwords - r.wbase > 0xffffffffull ? 0xffffffffu : (uint32_t)(nwords - r.wbase);
+	// positions are 32-bit, relative to the frame's first word; a stream that goes on for more
+	// than that is treated as endless
+	bool endless = false;
+	{
+		const uint64_t end_abs = live ? (streams[cd.stream].byte_offset + streams[cd.stream].byte_length) * 8 : 0;
+		const uint64_t rel = end_abs > r.wbase * 32 ? end_abs - r.wbase * 32 : 0;
+		endless = rel > 0xf0000000ull;
+		r.bend = endless ? 0xf0000000u : (uint32_t)rel;
+	}
+	r.ring = L.ring[lane];
+	// the first two chunks of every frame, all requested before the first is waited for
+	{
+		uint32_t first[2 * MAXLW];
+#pragma unroll
+		for (uint32_t ln = 0; ln < (uint32_t)MAXLW; ln++) {
+			const uint64_t wb = ((uint64_t)wave_value((uint32_t)(r.wbase >> 32), (int)ln) << 32) | wave_value((uint32_t)r.wbase, (int)ln);
+#pragma unroll
+			for (uint32_t c = 0; c < 2; c++) {
+				const uint64_t at = wb + c * RING_CHUNK + tid;
+				first[2 * ln + c] = (ln < LW && at < nwords) ? flac_words[at] : 0u;
+			}
+		}
+#pragma unroll
+		for (uint32_t ln = 0; ln < (uint32_t)MAXLW; ln++) {
+			L.ring[ln][tid] = __builtin_bswap32(first[2 * ln]);
+			L.ring[ln][RING_CHUNK + tid] = __builtin_bswap32(first[2 * ln + 1]);
+		}
+		r.limit = 2 * RING_CHUNK;
+	}
+	Pump pm;
+	for (int sl = 0; sl < PUMP_SLOTS; sl++) {
+		pm.lane[sl] = -1;
+		pm.data[sl] = 0;
+		pm.half[sl] = 0;
+	}
+	br_start(r, (uint32_t)(start_bit - r.wbase * 32));
+	const uint32_t bsf = cd.blocksize;
+	uint32_t bs_w = bsf;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t t = __shfl_xor(bs_w, o, 64);
+		bs_w = t > bs_w ? t : bs_w;
+	}
+	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * LW;
+	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
+
+	const uint32_t c_first = MODE == DEC_SUB ? only_c : 0;
+	const uint32_t c_end = MODE == DEC_SUB ? only_c + 1 : MODE == DEC_SKIP ? P.channels - 1 : P.channels;
+	for (uint32_t c = c_first; c < c_end; c++) {
+		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
+		if (MODE == DEC_SKIP && live)
+			sub_start[(size_t)j * P.channels + c] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
+		pump_service(pm, r, L, tid, live, nwords);
+		// ---- subframe header (stream_decoder.c:2450-2518) ----
+		SubHdr h;
+		h.kind = 0; h.order = 0; h.wasted = 0; h.po = 0; h.plen = 4; h.pesc = 15; h.psize = 0; h.shift = 0; h.lane_wide = false; h.constant = 0;
+		h.sbps = P.bps;
+		if ((cd.assignment == 1 && c == 1) || (cd.assignment == 2 && c == 0) || (cd.assignment == 3 && c == 1))
+			h.sbps++;
+		const bool ok_in = live && !r.err;
+		if (ok_in) {
+			uint32_t x = br_get(r, 8);
+			const uint32_t has_wasted = x & 1;
+			x &= 0xfe;
+			if (has_wasted) {
+				h.wasted = br_unary(r) + 1;
+				if (h.wasted >= h.sbps)
+					r.err = true;
+				else
+					h.sbps -= h.wasted;
+			}
+			// reserved type codes are "unparseable", a set padding bit is lost sync (stream_decoder.c:2476-2503)
+			if (x & 0x80) r.err = true;
+			else if (x == 0) h.kind = 0;
+			else if (x == 2) h.kind = 1;
+			else if (x < 16) r.err = reserved_code = true;
+			else if (x <= 24) {
+				h.kind = 2;
+				h.order = (x >> 1) & 7;
+				if (h.order > 4) r.err = true;
+			} else if (x < 64) r.err = reserved_code = true;
+			else {
+				h.kind = 3;
+				h.order = ((x >> 1) & 31) + 1;
+			}
+			if (h.order > bsf)
+				r.err = true;
+		}
+		if (ok_in && !r.err) {
+			if (h.kind == 0)
+				h.constant = br_get_signed(r, h.sbps);
+			if (h.kind >= 2) {
+				for (uint32_t i = 0; i < h.order; i++)
+					L.w[i][lane] = br_get_signed(r, h.sbps);
+				if (h.kind == 3) {
+					uint32_t prec = br_get(r, 4);
+					if (prec == 15)
+						r.err = true;  // stream_decoder.c:2622
+					prec++;
+					h.shift = br_get_signed(r, 5);
+					if (h.shift < 0)
+						h.shift = 0;  // the reference's shift by a negative count is undefined; it never writes one
+					for (uint32_t i = 0; i < h.order; i++)
+						L.q[i][lane] = br_get_signed(r, prec);
+					h.lane_wide = !(h.sbps + prec + d_ilog2(h.order) <= 32);  // stream_decoder.c:2676
+				} else {
+					for (uint32_t i = 0; i < h.order; i++)
+						L.q[i][lane] = c_fixed_q[h.order][i];
+				}
+				const uint32_t method = br_get(r, 2);
+				if (method > 1)
+					r.err = reserved_code = true;  // stream_decoder.c:2575,2654
+				if (method == 1) {
+					h.plen = 5;
+					h.pesc = 31;
+				}
+				h.po = br_get(r, 4);
+				// stream_decoder.c:2721-2739
+				h.psize = h.po > 0 ? bsf >> h.po : bsf - h.order;
+				if (h.po > 0 && (h.psize < h.order || (h.psize << h.po) != bsf))
+					r.err = true;
+			}
+			if (br_pos(r) > r.bend)
+				r.err = true;
+		}
+		// ---- samples, dispatched on what the wave as a whole needs ----
+		const bool predictive = h.kind >= 2 && live && !r.err;
+		uint32_t need = predictive ? h.order : 0;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const uint32_t t = __shfl_xor(need, o, 64);
+			need = t > need ? t : need;
+		}
+		const bool any_wide = __any(predictive && h.lane_wide);
+		const bool all24 = __all(!predictive || h.sbps <= 24);
+		const bool run = live && !r.err;
+#define DECODE(M) \
+	do { \
+		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+	} while (0)
+		if (MODE == DEC_SKIP) {
+			decode_samples<0, false, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords);
+			continue;
+		}
+		if (need == 0) DECODE(0);
+		else if (need <= 4) DECODE(4);
+		else if (need <= 8) DECODE(8);
+		else if (need <= 12) DECODE(12);
+		else if (need <= 16) DECODE(16);
+		else DECODE(32);
+#undef DECODE
+	}
+	if (MODE == DEC_SKIP) {
+		if (live) {
+			// where the last subframe starts; a frame that went wrong before that is finished here
+			if (br_pos(r) > r.bend)
+				r.err = true;
+			sub_start[(size_t)j * P.channels + P.channels - 1] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
+			if (r.err) {
+				const uint32_t bpos = br_pos(r);
+				const bool past = !endless && ((bpos > r.bend) || ((uint64_t)(bpos >> 3) + 2) * 8 > r.bend);
+				cands[j].end_byte = r.wbase * 4 + (bpos >> 3) + 2;
+				cands[j].status = past ? 4u : 2u;
+				cands[j].reserved = (!past && reserved_code) ? 1u : 0u;
+			}
+		}
+		return;
+	}
+	if (MODE == DEC_SUB && only_c + 1 != P.channels)
+		return;   // (a subframe the walk got through cannot fail here: the same bits, the same checks)
+	if (live) {
+		if (br_pos(r) > r.bend)
+			r.err = true;
+		// read_zero_padding_ (stream_decoder.c:2773): the pad bits must be zero
+		if (!r.err && (br_pos(r) & 7)) {
+			const uint32_t n = 8 - (br_pos(r) & 7);
+			if (br_get(r, n) != 0)
+				r.err = true;
+		}
+		const uint32_t bpos = br_pos(r);
+		const uint64_t end_byte = r.wbase * 4 + (bpos >> 3) + 2;
+		const bool past = !endless && ((bpos > r.bend) || ((uint64_t)(bpos >> 3) + 2) * 8 > r.bend);
+		if (past)
+			r.err = true;
+		cands[j].end_byte = end_byte;
+		// a parse that ran off the end of the input is a cut-off frame, not a malformed one
+		cands[j].status = past ? 4u : r.err ? 2u : 1u;
+		cands[j].reserved = (!past && r.err && reserved_code) ? 1u : 0u;
+	}
+}
+
+
+// what every dec_frames_*.hip defines: the launch of its instance
+#define DEC_FRAMES_LAUNCHER(name, MODE, MAXLW) \
+	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
+	          uint64_t *sub_start, uint32_t nwaves, hipStream_t st) \
+	{ \
+		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start); \
+	}
+
+#endif
