@@ -892,8 +892,11 @@ __device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint
 	}
 }
 
+#ifndef PQ_WAVES
+#define PQ_WAVES 4   // workgroups per CU (one wave of each per SIMD)
+#endif
 template <int HIST>
-__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PQ_WAVES, PQ_WAVES)))
 void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaPlan *__restrict__ plans,
                   const uint32_t *__restrict__ assign, uint32_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, uint32_t *errflag)
 {

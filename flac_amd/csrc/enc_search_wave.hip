@@ -263,8 +263,11 @@ struct SwCand {
 #define SW_REDO 0xffu   // plan type left by the two-taps launch for the one-tap launch to pick up
 
 // PAIRS: the samples are 16-bit stereo pairs, one 32-bit word per wide sample (the only layout compiled in then)
+#ifndef SW_WAVES
+#define SW_WAVES 4   // waves per SIMD: 128 registers each
+#endif
 template <int RES, bool PAIRS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SW_WAVES, SW_WAVES)))
 void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaLpcCand *__restrict__ cands,
                    const int32_t *__restrict__ coefs, FaPlan *__restrict__ plans, unsigned long long sig_list, uint32_t nsel)
 {
