@@ -20,6 +20,14 @@ def lib():
     return L.load(flac_amd.LIB_PATH)
 
 
+@pytest.fixture(params=["split", "lane"], autouse=True)
+def decoder_form(request, monkeypatch):
+    """Every case through both forms of the frame decoder: the split form (small batches of two or more channels take it
+    by default) and a lane per frame."""
+    monkeypatch.setenv("FLAC_AMD_DEC_MODE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("v", VECS, ids=[v["name"] for v in VECS])
 def test_batch_decoder(v):
     import flac_amd
