@@ -106,6 +106,38 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 				d[k] >>= wasted;
 			// the wide (64-bit) sums are only needed when a partial sum could pass 2^32
 			uint32_t t32[5] = {0, 0, 0, 0, 0};
+			if (P.bps <= 24) {
+				// Samples of up to 24 bits (25 for a side signal): no difference of up to the fourth order leaves 32 bits,
+				// so the errors are the absolute values of successive differences kept biased by 2^31 (a signed value
+				// and its biased form compare alike as unsigned numbers): |u - v| of two biased values is the unsigned
+				// absolute difference.  Four samples' worth (< 2^31) is added up in 32 bits before it goes into the
+				// 64-bit totals.
+				const uint32_t BIAS = 0x80000000u;
+				uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+				for (int k = 0; k < 4 + FA_CHUNK; k++) {
+					const uint32_t b0 = (uint32_t)d[k] ^ BIAS;
+					const uint32_t b1 = (b0 - p0) ^ BIAS, b2 = (b1 - p1) ^ BIAS, b3 = (b2 - p2) ^ BIAS;
+					if (k >= 4) {
+						const uint32_t idx = base + (uint32_t)(k - 4);
+						if (idx >= 4 && idx < bsf) {
+							t32[0] = sad_u32(b0, BIAS, t32[0]);
+							t32[1] = sad_u32(b0, p0, t32[1]);
+							t32[2] = sad_u32(b1, p1, t32[2]);
+							t32[3] = sad_u32(b2, p2, t32[3]);
+							t32[4] = sad_u32(b3, p3, t32[4]);
+						}
+						if (P.wide_fixed && (k & 3) == 3) {
+							te[0] += t32[0]; te[1] += t32[1]; te[2] += t32[2]; te[3] += t32[3]; te[4] += t32[4];
+							t32[0] = t32[1] = t32[2] = t32[3] = t32[4] = 0;
+						}
+					}
+					p0 = b0;
+					p1 = b1;
+					p2 = b2;
+					p3 = b3;
+				}
+			} else {
 #pragma unroll
 			for (int i = 0; i < FA_CHUNK; i++) {
 				const uint32_t idx = base + i;
@@ -119,6 +151,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 						t32[0] += e0; t32[1] += e1; t32[2] += e2; t32[3] += e3; t32[4] += e4;
 					}
 				}
+			}
 			}
 			if (!P.wide_fixed)
 				for (int k = 0; k < 5; k++)
