@@ -25,8 +25,12 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B, const void *pcm, FaSubStat *stats)
 {
-	const uint32_t task = blockIdx.x;
-	const uint32_t f = task / P.nsignals, s = task % P.nsignals;
+	// Workgroups go to the chip's eight dies in turn, each with an L2 of its own: the workgroups of one frame's
+	// signals, which read the same interleaved samples, are given indices that are equal modulo eight.
+	const uint32_t f = (blockIdx.x / (8 * P.nsignals)) * 8 + (blockIdx.x & 7u), s = (blockIdx.x % (8 * P.nsignals)) >> 3;
+	if (f >= B.nframes)
+		return;
+	const uint32_t task = f * P.nsignals + s;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
@@ -918,7 +922,7 @@ void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, 
 	if (B.pairs && P.nsignals == 4 && !P.wide_fixed)
 		hipLaunchKernelGGL(k_analyze_quad, dim3(B.nframes), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
 	else
-		hipLaunchKernelGGL(k_analyze, dim3(B.nframes * P.nsignals), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
+		hipLaunchKernelGGL(k_analyze, dim3((B.nframes + 7) / 8 * 8 * P.nsignals), dim3(FA_THREADS), 0, st, P, B, pcm, stats);
 }
 
 void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const float *windows, float *autoc,
