@@ -213,8 +213,15 @@ class Decoder:
         except Exception:
             pass
 
+    @staticmethod
+    def stream_array(streams):
+        """The descriptors of a batch as the C array flacamd_decode_streams takes: (byte_offset, byte_length, sample_offset,
+        total_samples[, first_sample]) each.  Building it costs a few microseconds per stream; a caller that decodes the same
+        batch layout again and again builds it once and passes it to decode_device in place of the list."""
+        return (StreamDesc * len(streams))(*[StreamDesc(*(tuple(s) + (0,) * (5 - len(s)))) for s in streams])
+
     def decode_device(self, flac_ptr, flac_bytes, streams, out_ptr, out_sample_bytes, out_capacity_wide, stream=None):
-        arr = (StreamDesc * len(streams))(*[StreamDesc(*(tuple(s) + (0,) * (5 - len(s)))) for s in streams])
+        arr = streams if isinstance(streams, C.Array) else self.stream_array(streams)
         _check(lib().flacamd_decode_streams(self._h, C.c_void_p(flac_ptr), C.c_uint64(flac_bytes), arr, len(streams),
                                             C.c_void_p(out_ptr), out_sample_bytes, C.c_uint64(out_capacity_wide),
                                             C.c_void_p(stream or 0)))
@@ -242,7 +249,9 @@ class Decoder:
         rows = (FrameInfo * capacity)()
         count, truncated = C.c_uint32(0), C.c_int(0)
         _check(lib().flacamd_decoder_frames(self._h, rows, capacity, C.byref(count), C.byref(truncated)))
-        return [rows[i] for i in range(count.value)]
+        if truncated.value:
+            raise FlacAmdError("the frame table holds more than the %d rows asked for (or more frames than the decoder's capacity)" % capacity)
+        return [rows[i] for i in range(min(count.value, capacity))]
 
     def set_profiling(self, on):
         _check(lib().flacamd_decoder_set_profiling(self._h, 1 if on else 0))

@@ -534,7 +534,9 @@ StaticLayout static_layout(const FaEncParams &P, size_t F)
 		return at;
 	};
 	const size_t S = P.nsignals;
-	L.windows = take(sizeof(float) * P.napod * P.blocksize);
+	// a fixed region whatever the call's settings: the tables are kept between calls, and a call with
+	// fewer or no window samples must not lay its other buffers over the tail of a kept table
+	L.windows = take(sizeof(float) * STATIC_MAX_WINDOW_FLOATS);
 	L.stats = take(sizeof(FaSubStat) * F * S);
 	L.autoc = take(sizeof(float) * F * S * P.napod * (FA_MAX_ORDER + 1));
 	L.cands = take(sizeof(FaLpcCand) * F * S * P.ncand);

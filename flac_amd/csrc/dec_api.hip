@@ -27,11 +27,8 @@ struct flacamd_decoder {
 	FaFrameCand *cands;
 	uint32_t *ncand;                // [0] count, [1] overflow flag
 	int32_t *tmp;
-	int32_t *vals;                  // cooperative form: values per (frame, channel) as read from the stream
-	FaSubDesc *subs;                // cooperative form: what the restore pass needs per (frame, channel)
-	uint32_t coop, coop_lw;         // the cooperative form is used, and its frames per group
-	uint64_t *sub_start;            // split form: bit position at which each (frame, channel)'s subframe starts
-	uint32_t split, skip_lw;        // the split form (walk, then a lane per subframe) is used; frames per wave of its walk
+	uint64_t *sub_start;            // bit position at which each (frame, channel)'s subframe starts
+	uint32_t split, skip_lw;        // the split form (walk, then every subframe at once) is used, not a launch per channel; frames per wave of its walk
 	unsigned long long *result;     // good frames, wide samples, bad candidates
 	int profiling, have_times;
 	hipEvent_t ev[FLACAMD_DEC_STAGES + 1];
@@ -53,8 +50,6 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipFree(d->cands);
 	(void)hipFree(d->ncand);
 	(void)hipFree(d->tmp);
-	(void)hipFree(d->vals);
-	(void)hipFree(d->subs);
 	(void)hipFree(d->sub_start);
 	(void)hipFree(d->result);
 	(void)hipFree(d->stage_in);
@@ -126,7 +121,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	{
 		const char *mode = getenv("FLAC_AMD_DEC_MODE");
 		const uint64_t units = (uint64_t)max_frames * channels;
-		d->split = channels >= 2 && units <= 40000 && !(mode && (!strcmp(mode, "lane") || !strcmp(mode, "coop")));
+		d->split = channels >= 2 && units <= 40000 && !(mode && !strcmp(mode, "lane"));
 		if (mode && !strcmp(mode, "split") && channels >= 2)
 			d->split = 1;
 		uint32_t lw = 4;
@@ -140,8 +135,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 			if ((max_frames + 15) / 16 > 3000)
 				lw = 32;
 		}
-		if (d->split)
-			ALLOC(d->sub_start, sizeof(uint64_t) * (size_t)max_frames * channels);
+		ALLOC(d->sub_start, sizeof(uint64_t) * (size_t)max_frames * channels);
 		if (const char *env = getenv("FLAC_AMD_DEC_LW")) {
 			const uint32_t v = (uint32_t)atoi(env);
 			if (v >= 1 && v <= (d->split ? 16u : 32u) && (v & (v - 1)) == 0)
@@ -158,21 +152,6 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 		d->skip_lw = slw;
 	}
 	ALLOC(d->result, 32);
-	// The cooperative form (dec_coop.hip: a wave per frame, then a lane per subframe) is an opt-in variant,
-	// FLAC_AMD_DEC_MODE=coop.  Measured against the lane-per-frame form it is 20-30 % faster on batches of up to
-	// ~4000 stereo frames and on eight-channel input, slower beyond (10 min of 16-bit stereo: 2.06 vs 1.79 ms), so
-	// the lane form stays the default.
-	{
-		d->coop = 0;
-		if (const char *env = getenv("FLAC_AMD_DEC_MODE"))
-			if (!strcmp(env, "coop"))
-				d->coop = 1;
-		d->coop_lw = fa_dec_coop_lw(channels);
-		if (d->coop) {
-			ALLOC(d->vals, sizeof(int32_t) * ((size_t)max_frames * channels * max_blocksize + 64));
-			ALLOC(d->subs, sizeof(FaSubDesc) * (size_t)max_frames * channels);
-		}
-	}
 #undef ALLOC
 	uint16_t t16[256], pow16[32];
 	uint8_t t8[256];
@@ -264,7 +243,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.nstreams = nstreams;
 	P.max_frames = d->max_frames;
 	P.number_scale = d->number_scale;
-	P.lw = d->coop ? d->coop_lw : d->lw;
+	P.lw = d->lw;
 	P.skip_lw = d->skip_lw;
 	P.pad = 0;
 	P.flac_bytes = flac_bytes;
@@ -281,10 +260,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, (size_t)out_capacity_wide * d->channels * out_sample_bytes, st));
 	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->block_offsets, d->cands, d->ncand, st);
 	STAGE_MARK();
-	if (d->coop)
-		fa_dec_launch_coop(P, flac_dev, d->streams, d->cands, d->ncand, d->vals, d->subs, d->tmp, st);
-	else
-		fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->split ? d->sub_start : nullptr, st);
+	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->sub_start, d->split != 0, st);
 	STAGE_MARK();
 	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, st);
 	STAGE_MARK();

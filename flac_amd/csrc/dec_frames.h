@@ -218,6 +218,10 @@ template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
                                                uint32_t bsf, bool live, uint64_t nwords)
 {
+	// (What the instances compute their addresses from is made opaque on the way in.  The single-pass kernel's loop
+	// over the channels holds all eighteen instances, and the compiler otherwise moves the address arithmetic of each
+	// in front of that loop, where it stays live throughout: several hundred registers.)
+	asm volatile("" : "+v"(tid), "+s"(LW));
 	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
 	// are switched on at the first residual; lanes without a predictor keep zeros
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
@@ -238,6 +242,70 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
 	// lanes that carry no frame write their block samples to a spare area
 	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * LDS::maxlw];
+	// the partition parameter(s) due at sample i (stream_decoder.c:2741-2767); the predictor is switched on with the first
+	auto read_part = [&](uint32_t i) __attribute__((always_inline)) {
+		if (M > 0 && i == h.order) {
+#pragma unroll
+			for (int j = 0; j < M; j++)
+				q[j] = (uint32_t)j < h.order ? L.q[j][lane] : 0;
+		}
+		// a first partition as long as the warm-up holds no residual but still has its
+		// parameter in the stream (stream_decoder.c:2734 lets it through, :2747-2767
+		// reads it): its successor's parameter follows at once
+		do {
+			k = br_get(r, h.plen);
+			escape = k >= h.pesc;
+			if (escape) {
+				raw_bits = br_get(r, 5);
+				k = 0;
+			}
+			part_end = h.po > 0 ? part_end + h.psize : bsf;
+		} while (part_end <= i && !r.err && br_pos(r) <= r.bend);
+		kp1 = k + 1;
+		next_part = part_end;
+		seg_end = escape ? 0 : next_part;
+	};
+	// one sample through the predictor: the value, which also becomes the newest history entry
+	auto restore = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
+		int32_t v = res;
+		if (M > 0) {
+			int32_t pred;
+			if (WIDE) {
+				int64_t sum = 0;
+#pragma unroll
+				for (int j = 0; j < M; j++)
+					sum += (int64_t)q[j] * (int64_t)hist[j];
+				pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
+			} else {
+				int32_t sum = 0;
+				if (MUL24) {
+					// two chains of 24-bit multiply-adds, one instruction per tap
+					int32_t s0, s1 = 0;
+					asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(hist[0]));
+					if (M > 1)
+						asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(hist[1]));
+#pragma unroll
+					for (int j = 2; j < M; j += 2) {
+						asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(q[j]), "v"(hist[j]), "v"(s0));
+						if (j + 1 < M)
+							asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(q[j + 1]), "v"(hist[j + 1]), "v"(s1));
+					}
+					sum = s0 + s1;
+				} else {
+#pragma unroll
+					for (int j = 0; j < M; j++)
+						sum += q[j] * hist[j];
+				}
+				pred = sum >> h.shift;
+			}
+			v = (int32_t)((uint32_t)res + (uint32_t)pred);
+#pragma unroll
+			for (int j = M - 1; j > 0; j--)
+				hist[j] = hist[j - 1];
+			hist[0] = v;
+		}
+		return v;
+	};
 	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
 		pump_service(pm, r, L, tid, live, nwords);
 		if (br_pos(r) > r.bend) {
@@ -245,6 +313,83 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			work_end = 0;
 			seg_end = 0;
 		}
+		// A partition that starts with the block (partitions of 16 k samples always do) has its parameter read here, so
+		// that the block itself is nothing but symbols.
+		if (i0 < work_end && h.kind >= 2 && i0 == next_part) {
+			read_part(i0);
+			if (r.err) {
+				work_end = 0;
+				seg_end = 0;
+			}
+		}
+		// ---- the plain block ----
+		// Most blocks are sixteen Rice symbols of one parameter for every lane that is still reading, each symbol inside
+		// the next 32 bits, all words in the ring.  Such a block runs without a single branch or comparison against the
+		// sample index: count of leading zeros, saturating add, the window stepped on by at most one word (the word after
+		// next and the one after that are held in registers, the second requested a symbol before it can be needed), and
+		// the largest symbol length seen is looked at once, afterwards.  Should a symbol have been longer than 32 bits (or
+		// the stream have run out into the zeros behind it), nothing is kept and the block is done again the careful way.
+		// Lanes with nothing to read (constant subframes, finished or broken frames, lanes without a frame) compute
+		// garbage alongside and are put right at the end.
+		const bool idle = i0 >= work_end;
+		const bool plain = i0 + DEC_BLOCK <= seg_end && i0 + DEC_BLOCK <= work_end && r.wrel + 2 * DEC_BLOCK < r.limit;
+		bool block_done = false;
+		if (__all(idle || plain)) {
+			uint32_t cur = r.cur, nxt = r.nxt, rem = r.rem, wrel = r.wrel;
+			uint32_t n2 = r.ring[wrel & (RING_WORDS - 1)], n3 = r.ring[(wrel + 1) & (RING_WORDS - 1)];
+			uint32_t tmax = 0;
+			// the history as it is now, in case the block has to be done again: kept in the warm-up samples' place in
+			// LDS, which nobody reads any more once a partition parameter has been read (a second copy in registers
+			// costs up to 32 of them, and the single-pass instances their second wave per SIMD)
+			if (M > 0 && tid < LW) {
+#pragma unroll
+				for (int j = 0; j < M; j++)
+					L.w[j][lane] = hist[j];
+			}
+#pragma unroll
+			for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+				const uint32_t win = __builtin_amdgcn_alignbit(cur, nxt, rem);
+				uint32_t z, total;
+				asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
+				asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
+				tmax = total > tmax ? total : tmax;
+				const int32_t left = (int32_t)rem - (int32_t)total;
+				const bool cross = left < 0;
+				cur = cross ? nxt : cur;
+				nxt = cross ? n2 : nxt;
+				n2 = cross ? n3 : n2;
+				wrel += cross ? 1u : 0u;
+				rem = (uint32_t)left & 31u;
+				n3 = r.ring[(wrel + 1) & (RING_WORDS - 1)];
+				if (!SKIP) {
+					const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
+					const uint32_t uf = (z << k) | lsbs;
+					const int32_t res = (int32_t)(uf >> 1) ^ __builtin_amdgcn_sbfe((int32_t)uf, 0, 1);
+					slot[s * LW] = (int32_t)((uint32_t)restore(res) << h.wasted);
+				}
+			}
+			if (!__any(plain && tmax > 32)) {
+				if (plain) {
+					r.cur = cur;
+					r.nxt = nxt;
+					r.rem = rem;
+					r.wrel = wrel;
+				}
+				if (!SKIP && __any(idle && tid < LW)) {
+					if (idle) {
+#pragma unroll
+						for (uint32_t s = 0; s < DEC_BLOCK; s++)
+							slot[s * LW] = (int32_t)((uint32_t)h.constant << h.wasted);
+					}
+				}
+				block_done = true;
+			} else if (M > 0 && tid < LW) {
+#pragma unroll
+				for (int j = 0; j < M; j++)
+					hist[j] = L.w[j][lane];
+			}
+		}
+		if (!block_done) {
 		// the fast path takes at most one word per sample
 		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 		// SKIP: a sample is half a dozen instructions, fewer cycles than an LDS read takes, so the ring is read two
@@ -292,28 +437,8 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					if (i < h.order)
 						res = L.w[i][lane];
 					else {
-						if (i == next_part) {
-							if (M > 0 && i == h.order) {
-#pragma unroll
-								for (int j = 0; j < M; j++)
-									q[j] = (uint32_t)j < h.order ? L.q[j][lane] : 0;
-							}
-							// a first partition as long as the warm-up holds no residual but still has its
-							// parameter in the stream (stream_decoder.c:2734 lets it through, :2747-2767
-							// reads it): its successor's parameter follows at once
-							do {
-								k = br_get(r, h.plen);
-								escape = k >= h.pesc;
-								if (escape) {
-									raw_bits = br_get(r, 5);
-									k = 0;
-								}
-								part_end = h.po > 0 ? part_end + h.psize : bsf;
-							} while (part_end <= i && !r.err && br_pos(r) <= r.bend);
-							kp1 = k + 1;
-							next_part = part_end;
-							seg_end = escape ? 0 : next_part;
-						}
+						if (i == next_part)
+							read_part(i);
 						if (!escape) {
 							const uint32_t msbs = br_unary(r);
 							const uint32_t low = br_get(r, k);
@@ -334,45 +459,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
 				}
 			}
-			int32_t v = res;
-			if (M > 0) {
-				int32_t pred;
-				if (WIDE) {
-					int64_t sum = 0;
-#pragma unroll
-					for (int j = 0; j < M; j++)
-						sum += (int64_t)q[j] * (int64_t)hist[j];
-					pred = h.lane_wide ? (int32_t)(sum >> h.shift) : ((int32_t)sum >> h.shift);
-				} else {
-					int32_t sum = 0;
-					if (MUL24) {
-						// two chains of 24-bit multiply-adds, one instruction per tap
-						int32_t s0, s1 = 0;
-						asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(hist[0]));
-						if (M > 1)
-							asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(hist[1]));
-#pragma unroll
-						for (int j = 2; j < M; j += 2) {
-							asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(q[j]), "v"(hist[j]), "v"(s0));
-							if (j + 1 < M)
-								asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(q[j + 1]), "v"(hist[j + 1]), "v"(s1));
-						}
-						sum = s0 + s1;
-					} else {
-#pragma unroll
-						for (int j = 0; j < M; j++)
-							sum += q[j] * hist[j];
-					}
-					pred = sum >> h.shift;
-				}
-				v = (int32_t)((uint32_t)res + (uint32_t)pred);
-#pragma unroll
-				for (int j = M - 1; j > 0; j--)
-					hist[j] = hist[j - 1];
-				hist[0] = v;
-			}
+			const int32_t v = restore(res);
 			if (!SKIP)
 				slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
+		}
 		}
 		if (!SKIP) {
 			// the block goes out with all 64 threads along memory order
@@ -383,35 +473,45 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	}
 }
 
-// One lane per frame; a wave carries LW <= 16 frames in its first lanes, the other lanes only help
-// moving data.  A wave's pace is set by its longest dependent chain, not by how many of its lanes
+// One lane per subframe; a wave carries one channel of LW <= MAXLW frames in its first lanes, the other lanes
+// only help moving data.  A wave's pace is set by its longest dependent chain, not by how many of its lanes
 // decode, so a batch is spread over as many waves as the chip can run at once.
 //
 // The chain is a frame's samples one after the other, and a subframe can only be started where the one
-// before it ends.  For batches that leave the chip room, the chain is cut: DEC_SKIP walks the subframes
-// of every channel but the last without decoding them (a symbol's length is all it takes: a quarter of
-// the instructions) and leaves the bit position at which each subframe starts; DEC_SUB then runs one lane
-// per (frame, channel), a wave taking one channel of LW frames, so the longest chain is one subframe.
-// A frame the walk found malformed gets its status there and is left alone by DEC_SUB; the lane of the
-// last channel finishes the frame (padding, end, status) as the single pass does.
-#define DEC_WHOLE 0
+// before it ends.  DEC_SUB decodes the subframe that starts at a known bit position (sub_start, or the end of
+// the frame header for channel 0 of a chained pass); who knows the positions depends on the batch:
+//   chained (chain = c): one launch per channel, in channel order.  Launch c decodes channel c of every frame
+//     and leaves where channel c + 1 starts; nothing is walked twice.  For batches that fill the chip anyway.
+//   split (chain = DEC_NO_CHAIN): DEC_SKIP first walks the subframes of every channel but the last without
+//     decoding them (a symbol's length is all it takes: less than half the instructions) and leaves every
+//     start; then one DEC_SUB launch runs all (frame, channel) pairs at once, so the longest chain is one
+//     subframe.  For batches that leave the chip room.
+// A frame found malformed before its last subframe gets its status where that is found and is left alone
+// afterwards; the lane of the last channel finishes the frame (padding, end, status).
+// (A kernel that loops over the channels with a lane per frame is the obvious third form and was the first one
+// here; with two bodies per sample block the compiler needs more than 512 registers for it, and one launch per
+// channel is that loop without its cost.)
+#define DEC_NO_CHAIN 0xffffffffu
 #define DEC_SKIP 1
 #define DEC_SUB 2
 #define DEC_NO_START 0xffffffffffffffffull
 
 template <int MODE, int MAXLW>
-__global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
-                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start)
+__global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
+                                                          FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start,
+                                                          uint32_t chain)
 {
 	__shared__ DecLds<MAXLW> L;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ncand = ncand_ptr[0];
-	const uint32_t grp = MODE == DEC_SUB ? blockIdx.x / P.channels : blockIdx.x;
-	const uint32_t only_c = MODE == DEC_SUB ? blockIdx.x % P.channels : 0;
+	const bool chained = MODE == DEC_SUB && chain != DEC_NO_CHAIN;
+	const uint32_t grp = (MODE == DEC_SUB && !chained) ? blockIdx.x / P.channels : blockIdx.x;
+	const uint32_t only_c = MODE == DEC_SUB ? (chained ? chain : blockIdx.x % P.channels) : 0;
 	if (grp * LW >= ncand)
 		return;
 	const uint32_t j = grp * LW + tid;
-	bool live = tid < LW && j < ncand;
+	const bool have_frame = tid < LW && j < ncand;
+	bool live = have_frame;
 	const uint32_t lane = tid < (uint32_t)MAXLW ? tid : 0;
 	FaFrameCand cd;
 	if (live)
@@ -421,10 +521,10 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	}
 	// where the lane starts reading, in bits from the start of the input
 	uint64_t start_bit = (cd.pos + cd.hdr_bytes) * 8;
-	if (MODE == DEC_SUB) {
+	if (MODE == DEC_SUB && !(chained && only_c == 0)) {
 		if (live) {
 			start_bit = sub_start[(size_t)j * P.channels + only_c];
-			if (start_bit == DEC_NO_START) {
+			if (start_bit >= P.flac_bytes * 8) {   // DEC_NO_START: the frame ended in an earlier subframe
 				live = false;
 				start_bit = 0;
 			}
@@ -483,7 +583,7 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
 
 	const uint32_t c_first = MODE == DEC_SUB ? only_c : 0;
-	const uint32_t c_end = MODE == DEC_SUB ? only_c + 1 : MODE == DEC_SKIP ? P.channels - 1 : P.channels;
+	const uint32_t c_end = MODE == DEC_SUB ? only_c + 1 : P.channels - 1;
 	for (uint32_t c = c_first; c < c_end; c++) {
 		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
 		if (MODE == DEC_SKIP && live)
@@ -606,8 +706,25 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 		}
 		return;
 	}
-	if (MODE == DEC_SUB && only_c + 1 != P.channels)
-		return;   // (a subframe the walk got through cannot fail here: the same bits, the same checks)
+	if (MODE == DEC_SUB && only_c + 1 != P.channels) {
+		// split: a subframe the walk got through cannot fail here (the same bits, the same checks).  Chained: this
+		// pass is the only one that looks at the subframe, so it says where the next one starts, or that the frame ends here
+		if (chained && have_frame && !live)
+			sub_start[(size_t)j * P.channels + only_c + 1] = DEC_NO_START;
+		if (chained && live) {
+			if (br_pos(r) > r.bend)
+				r.err = true;
+			sub_start[(size_t)j * P.channels + only_c + 1] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
+			if (r.err) {
+				const uint32_t bpos = br_pos(r);
+				const bool past = !endless && ((bpos > r.bend) || ((uint64_t)(bpos >> 3) + 2) * 8 > r.bend);
+				cands[j].end_byte = r.wbase * 4 + (bpos >> 3) + 2;
+				cands[j].status = past ? 4u : 2u;
+				cands[j].reserved = (!past && reserved_code) ? 1u : 0u;
+			}
+		}
+		return;
+	}
 	if (live) {
 		if (br_pos(r) > r.bend)
 			r.err = true;
@@ -633,9 +750,9 @@ __global__ __launch_bounds__(DEC_LANES) void k_dec_frames(FaDecParams P, const u
 // what every dec_frames_*.hip defines: the launch of its instance
 #define DEC_FRAMES_LAUNCHER(name, MODE, MAXLW) \
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
-	          uint64_t *sub_start, uint32_t nwaves, hipStream_t st) \
+	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st) \
 	{ \
-		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start); \
+		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
 	}
 
 #endif

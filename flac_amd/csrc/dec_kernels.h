@@ -34,31 +34,14 @@ struct FaFrameCand {
 	uint32_t reserved;   // keeps the row the size and layout of flacamd_frame_info
 };
 
-// What the cooperative entropy pass leaves for the restore pass about one (frame, channel).
-struct FaSubDesc {
-	uint32_t kind;       // 0 constant, 1 verbatim, 2 fixed, 3 lpc
-	uint32_t order;      // predictor order (0 for constant / verbatim)
-	uint32_t wasted;
-	uint32_t sbps;       // bits per sample of the subframe, wasted bits removed
-	int32_t shift;
-	uint32_t wide;       // the restore needs the 64-bit sum (stream_decoder.c:2676)
-	int32_t constant;
-	uint32_t pad;
-	int32_t q[FA_MAX_ORDER];
-};
-
 hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
 void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
                         FaFrameCand *cands, uint32_t *ncand, hipStream_t st);
-// sub_start: null for a lane per frame; else max_frames * channels words for the split form (a walk that leaves
-// where every subframe starts, then a lane per subframe)
+// sub_start: max_frames * channels words, the bit position at which each (frame, channel)'s subframe starts.
+// split: a walk that leaves every start, then a lane per subframe in one launch; else one launch per channel
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, uint64_t *sub_start, hipStream_t st);
-// the cooperative form for batches of few frames (dec_coop.hip): entropy pass + restore pass in place of fa_dec_launch_frames
-uint32_t fa_dec_coop_lw(uint32_t channels);
-void fa_dec_launch_coop(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *vals,
-                        FaSubDesc *subs, int32_t *tmp, hipStream_t st);
+                          int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st);
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st);
 void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
                           void *out, unsigned long long *result, hipStream_t st);

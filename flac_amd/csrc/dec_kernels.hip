@@ -687,27 +687,29 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
 // the instances of k_dec_frames, each in a translation unit of its own (dec_frames_*.hip)
 #define DEC_FRAMES_DECL(name) \
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
-	          uint64_t *sub_start, uint32_t nwaves, hipStream_t st)
-DEC_FRAMES_DECL(fa_dec_frames_whole16);
-DEC_FRAMES_DECL(fa_dec_frames_whole32);
+	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st)
 DEC_FRAMES_DECL(fa_dec_frames_skip16);
 DEC_FRAMES_DECL(fa_dec_frames_sub16);
+DEC_FRAMES_DECL(fa_dec_frames_sub32);
 
+// split: walk, then every (frame, channel) at once; else one launch per channel, in order (see dec_frames.h)
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, uint64_t *sub_start, hipStream_t st)
+                          int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st)
 {
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
 	const uint32_t *words = (const uint32_t *)flac;
-	if (sub_start && P.channels >= 2 && P.lw <= 16 && P.skip_lw <= 16) {
-		fa_dec_frames_skip16(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, (P.max_frames + P.skip_lw - 1) / P.skip_lw, st);
-		fa_dec_frames_sub16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups * P.channels, st);
+	if (split && P.channels >= 2 && P.lw <= 16 && P.skip_lw <= 16) {
+		fa_dec_frames_skip16(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, (P.max_frames + P.skip_lw - 1) / P.skip_lw, 0xffffffffu, st);
+		fa_dec_frames_sub16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups * P.channels, 0xffffffffu, st);
 		return;
 	}
-	// a lane per frame; the largest batches put 32 frames into a wave (twice the LDS, half the waves)
-	if (P.lw <= 16)
-		fa_dec_frames_whole16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, st);
-	else
-		fa_dec_frames_whole32(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, st);
+	// the largest batches put 32 frames into a wave (twice the LDS, half the waves)
+	for (uint32_t c = 0; c < P.channels; c++) {
+		if (P.lw <= 16)
+			fa_dec_frames_sub16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+		else
+			fa_dec_frames_sub32(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+	}
 }
 
 void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)

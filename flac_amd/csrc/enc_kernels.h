@@ -16,6 +16,9 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
                       const int32_t *coefs, FaPlan *plans, unsigned long long *stamps, hipStream_t st);
 // the wave-per-subframe form of the search (enc_search_wave.hip) for the listed signals of every frame
 bool fa_search_wave_eligible(const FaEncParams &P);
+bool fa_search_wave_split_eligible(const FaEncParams &P);
+void fa_launch_search_wave_split(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
+                                 const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, hipStream_t st);
 void fa_launch_search_wave(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
                            const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, unsigned long long wide_list, uint32_t nwide,
                            hipStream_t st);

@@ -978,7 +978,14 @@ void fa_launch_search(const FaEncParams &P, const FaBatch &B, const void *pcm, c
 	{
 		const char *mode = getenv("FLAC_AMD_SEARCH");
 		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
-		if (!generic_only && fa_search_wave_eligible(P)) {
+		if (!generic_only && !B.pairs && fa_search_wave_split_eligible(P)) {
+			// 20- to 24-bit streams: every signal to the split-sample form of the wave search
+			unsigned long long all = 0;
+			for (uint32_t sg = 0; sg < P.nsignals; sg++)
+				all |= (unsigned long long)sg << (4 * sg);
+			fa_launch_search_wave_split(P, B, pcm, stats, cands, coefs, plans, all, P.nsignals, st);
+			first_dot2 = first_taps = B.nframes;
+		} else if (!generic_only && fa_search_wave_eligible(P)) {
 			unsigned long long wl = 0, wide = 0;
 			uint32_t wn = 0, nwide = 0, left = 0;
 			for (uint32_t sg = 0; sg < P.nsignals; sg++) {

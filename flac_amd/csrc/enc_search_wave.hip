@@ -60,6 +60,97 @@ __device__ __forceinline__ void sw_negres_dot2(const int32_t (&PW)[SW_W], const 
 	}
 }
 
+// The same for samples wider than 16 bits (up to 25): a sample is s = sh 2^12 + sl with sl its low 12 bits, both halves
+// fit a 16-bit lane, so the folded sum  S = sum q[j] d[i-1-j] - d[i] 2^shift  is  A 2^12 + B  with A and B one chain
+// of v_dot2_i32_i16 each (Ph / Pl: the halves as pairs, laid out like PW above).  What the reference does with S
+// decides how A and B are put together (the candidate's fold, worked out once per candidate by sw_split_fold):
+//   SWF_W  wrapping 32-bit sum (lpc.c:265)            x = ((A << 12) + B) >> shift        B = 2^(31-shift)
+//   SWF_S  64-bit sum (lpc.c:531), shift <= 12        x = (A << (12-shift)) + (B >> shift) B = 2^31: A 2^12 is a multiple of
+//                                                     2^shift, so floor(S / 2^shift) splits exactly
+//   SWF_L  64-bit sum, shift > 12                     x = (A + (B >> 12)) >> (shift-12)    B = 2^(43-shift): the low 12 bits
+//                                                     of B cannot carry, floor(S / 2^shift) = floor((A + floor(B / 2^12)) / 2^(shift-12))
+// with x = B - residual as in the 16-bit form: the 2^31 rides in A's starting value a0 = 2^31 >> (A's left shift), the
+// outer shift is logical, B's inner one arithmetic.  Exact while |S| (and B itself, where it is shifted) stay inside
+// 32 bits, which sw_split_fold checks from the sum of the coefficients' magnitudes.
+#define SWF_W 0
+#define SWF_S 1
+#define SWF_L 2
+
+struct SwFold {
+	uint32_t form, sa, sb, sc, a0;
+	bool exact;
+};
+
+__device__ __forceinline__ SwFold sw_split_fold(uint64_t sumq, uint32_t shift, uint32_t sbps, bool wide64)
+{
+	SwFold f;
+	const uint64_t lim = 1ull << 31;
+	const uint64_t all = sumq + (1ull << shift);                  // the folded chain's coefficient magnitudes
+	const bool b_fits = all * 4095u < lim;                        // |B| <= all * (2^12 - 1)
+	if (!wide64) {
+		f.form = SWF_W; f.sa = 12; f.sb = 0; f.sc = shift;
+		f.exact = fa_fold_exact(sumq, shift, sbps);
+	} else if (shift <= 12) {
+		f.form = SWF_S; f.sa = 12 - shift; f.sb = shift; f.sc = 0;
+		// |prediction - sample| <= (sumq / 2^shift + 1) 2^(sbps-1), rounded up
+		f.exact = b_fits && (((sumq >> shift) + 2) << (sbps - 1)) < lim;
+	} else {
+		f.form = SWF_L; f.sa = 0; f.sb = 12; f.sc = shift - 12;
+		// |A + (B >> 12)| <= all * 2^(sbps-1) / 2^12, rounded up
+		f.exact = shift <= 15 && b_fits && ((all << (sbps > 13 ? sbps - 13 : 0)) + (1u << 19)) < lim;
+	}
+	f.a0 = 0x80000000u >> f.sa;
+	return f;
+}
+
+template <int OFF, int JJ>
+__device__ __forceinline__ void sw_split_groups(const int32_t (&Ph)[SW_W], const int32_t (&Pl)[SW_W], const int32_t (&qf)[SW_NQF], uint32_t order,
+                                                int32_t (&A)[16], int32_t (&Bs)[16])
+{
+	if constexpr (JJ < SW_NQF) {
+		if ((uint32_t)(2 * JJ) <= order) {
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				A[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, Ph[SW_HIST + OFF + i - 2 * JJ]), __builtin_bit_cast(fa_short2, qf[JJ]), A[i], false);
+				Bs[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(fa_short2, Pl[SW_HIST + OFF + i - 2 * JJ]), __builtin_bit_cast(fa_short2, qf[JJ]), Bs[i], false);
+			}
+			sw_split_groups<OFF, JJ + 1>(Ph, Pl, qf, order, A, Bs);
+		}
+	}
+}
+
+template <int OFF>
+__device__ __forceinline__ void sw_negres_split(const int32_t (&Ph)[SW_W], const int32_t (&Pl)[SW_W], const int32_t (&qf)[SW_NQF], uint32_t order,
+                                                const SwFold &f, uint32_t a0v, uint32_t (&x)[16])
+{
+	int32_t A[16], Bs[16];
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(A[i]) : "v"(Ph[SW_HIST + OFF + i]), "s"(qf[0]), "v"(a0v));
+		asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(Bs[i]) : "v"(Pl[SW_HIST + OFF + i]), "s"(qf[0]));
+	}
+	sw_split_groups<OFF, 1>(Ph, Pl, qf, order, A, Bs);
+	if (f.form == SWF_W) {
+		if (f.sc) {
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				x[i] = (((uint32_t)A[i] << 12) + (uint32_t)Bs[i]) >> f.sc;
+		} else {   // the fixed predictors
+#pragma unroll
+			for (int i = 0; i < 16; i++)
+				x[i] = ((uint32_t)A[i] << 12) + (uint32_t)Bs[i];
+		}
+	} else if (f.form == SWF_S) {
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			x[i] = ((uint32_t)A[i] << f.sa) + (uint32_t)(Bs[i] >> f.sb);
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			x[i] = ((uint32_t)A[i] + (uint32_t)(Bs[i] >> 12)) >> f.sc;
+	}
+}
+
 // the warm-up samples (the first `order` of the frame: lane 0, first block only) count as zero
 template <int I>
 __device__ __forceinline__ void sw_warm_up(uint32_t (&x)[16], uint32_t Bc, uint32_t order, bool lane0)
@@ -175,7 +266,7 @@ __device__ __forceinline__ SwLane sw_lane_items(uint32_t ln, uint32_t pm, uint32
 	return L;
 }
 
-__device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn, uint32_t order, uint32_t seed, uint32_t bsf, uint32_t rice_limit,
+__device__ __forceinline__ void sw_price(uint64_t fr64, uint32_t pm, uint32_t pmn, uint32_t order, uint32_t seed, uint32_t bsf, uint32_t rice_limit,
                                          uint32_t lane, const SwLane &L, uint32_t &bestb_out, uint32_t &bestpo_out, uint32_t &kpair_out)
 {
 	const bool mine = L.mine, have_c = L.have_c;
@@ -183,7 +274,8 @@ __device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn,
 	const uint32_t nf = (bsf >> pm) - (L.lane0 ? order : 0u);
 	const uint32_t nc = (bsf >> poc) - (L.pc0 ? order : 0u);
 	// 32-bit arithmetic when every finest sum is below 2^26 (no sum of 64 of them reaches 2^32)
-	const bool narrow = __all((fr >> 26) == 0);
+	const bool narrow = __all((fr64 >> 26) == 0);
+	const uint32_t fr = (uint32_t)fr64;
 	uint32_t bf, bc, kf, kc;
 	if (narrow) {
 		const uint32_t incl = sw_scan_incl(fr);
@@ -202,7 +294,7 @@ __device__ __forceinline__ void sw_price(uint32_t fr, uint32_t pm, uint32_t pmn,
 		const uint32_t pc = ln & ((1u << poc) - 1u);
 		const uint32_t src = (2u * pc + 1u) << ((pm - 1u - poc) & 31u);   // the lane that holds the item's sum after the exchanges
 		uint64_t v[7];
-		v[0] = fr;
+		v[0] = fr64;
 #pragma unroll
 		for (int j = 0; j < 6; j++)
 			v[j + 1] = v[j] + (uint64_t)__shfl_xor((unsigned long long)v[j], 1 << j, 64);
@@ -260,6 +352,7 @@ struct SwCand {
 
 #define SW_TAPS 0
 #define SW_DOT2 1
+#define SW_SPLIT 2   // samples of up to 25 bits as two 16-bit halves (sw_negres_split): streams wider than 16 bits
 #define SW_REDO 0xffu   // plan type left by the two-taps launch for the one-tap launch to pick up
 
 // PAIRS: the samples are 16-bit stereo pairs, one 32-bit word per wide sample (the only layout compiled in then)
@@ -267,7 +360,7 @@ struct SwCand {
 #define SW_WAVES 4   // waves per SIMD: 128 registers each
 #endif
 template <int RES, bool PAIRS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SW_WAVES, SW_WAVES)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES == SW_SPLIT ? 2 : SW_WAVES, RES == SW_SPLIT ? 2 : SW_WAVES)))
 void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaLpcCand *__restrict__ cands,
                    const int32_t *__restrict__ coefs, FaPlan *__restrict__ plans, unsigned long long sig_list, uint32_t nsel)
 {
@@ -295,6 +388,8 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 	const uint32_t hdr = 8 + wasted;
 	// process_subframes_ (stream_encoder.c:2929-2936): a full block has twelve factors of two, a short
 	// one is coded with partition order 0; format.c:548 never lowers the limit here (64 > 12)
+	// (a full block of a stream whose limit is below 6 has coarser finest partitions than a lane's run: the sums of
+	// 2^(6 - pm) lanes are put together in consider())
 	const uint32_t pm = partial ? 0u : umin32(P.max_po, 6u);
 	const uint32_t pmn = umin32(P.min_po, pm);
 
@@ -347,6 +442,17 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 				w[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)d[k], (uint32_t)d[k - 1], 0x05040100u);
 			w[0] = (int32_t)((uint32_t)d[0] << 16);
 		}
+		// the split form: w becomes the high halves' pairs, wl the low halves' (12 bits, unsigned)
+		int32_t wl[RES == SW_SPLIT ? SW_W : 1];
+		if constexpr (RES == SW_SPLIT) {
+#pragma unroll
+			for (int k = SW_W - 1; k >= 1; k--) {
+				wl[k] = (int32_t)((((uint32_t)d[k] & 0xfffu) << 16) | ((uint32_t)d[k - 1] & 0xfffu));
+				w[k] = (int32_t)__builtin_amdgcn_perm((uint32_t)(d[k] >> 12), (uint32_t)(d[k - 1] >> 12), 0x05040100u);
+			}
+			wl[0] = (int32_t)(((uint32_t)d[0] & 0xfffu) << 16);
+			w[0] = (int32_t)((uint32_t)(d[0] >> 12) << 16);
+		}
 		const uint32_t fold_bps = RES == SW_DOT2 ? umin32(sbps, 16u) : sbps;
 		const uint32_t c31 = 0x80000000u;
 		const bool lane0 = ln == 0;
@@ -377,9 +483,25 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 			fx = __builtin_amdgcn_readfirstlane(fx);
 		}
 
+		// The words of LPC candidate c as they lie in memory, still in vector registers: with two waves per SIMD (the
+		// split form) there is too little else going on to hide two dependent trips to memory per candidate, so that
+		// form asks for candidate c + 1's words before it starts on candidate c.
+		struct SwRaw {
+			uint2 head;
+			int32_t q[SW_HIST];
+		};
+		auto fetch = [&](uint32_t c, SwRaw &r) {
+			if (c >= 5 && c < total_cands) {
+				r.head = *(const uint2 *)(my_cands + (c - 5));
+				const int32_t *cq = my_coefs + (c - 5) * max_lpc_order;
+#pragma unroll
+				for (int j = 0; j < SW_HIST; j++)
+					r.q[j] = cq[j];   // the buffer ends in slack, so the twelve reads are always inside it
+			}
+		};
 		// candidate c of the reference's trial order: fixed orders ascending, then the LPC candidates as
-		// k_lpc listed them.  False: it does not take part.
-		auto candidate = [&](uint32_t c, SwCand &k) -> bool {
+		// k_lpc listed them.  False: it does not take part.  pre: its words, fetched earlier (else they are read here).
+		auto candidate = [&](uint32_t c, SwCand &k, const SwRaw *pre = nullptr) -> bool {
 #pragma unroll
 			for (int j = 0; j < SW_HIST; j++)
 				k.q[j] = 0;
@@ -406,7 +528,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 			}
 			const uint32_t slot = c - 5;
 			// (the slot is the same in every lane: its words and the coefficients below belong in scalar registers)
-			const uint2 lcw = *(const uint2 *)(my_cands + slot);
+			const uint2 lcw = pre ? pre->head : *(const uint2 *)(my_cands + slot);
 			const uint32_t w0 = __builtin_amdgcn_readfirstlane(lcw.x), w1 = __builtin_amdgcn_readfirstlane(lcw.y);
 			if (!(w0 & 0xffu))   // FaLpcCand: valid, order, precision, shift | rice, wide, sumq32
 				return false;
@@ -423,7 +545,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 			const int32_t *cq = my_coefs + slot * max_lpc_order;
 #pragma unroll
 			for (int j = 0; j < SW_HIST; j++) {
-				const int32_t qj = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)cq[j]);   // the buffer ends in slack, so the twelve reads are always inside it
+				const int32_t qj = (int32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pre ? pre->q[j] : cq[j]));   // the buffer ends in slack, so the twelve reads are always inside it
 				k.q[j] = (uint32_t)j < order ? qj : 0;
 			}
 			return true;
@@ -434,13 +556,26 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		auto consider = [&](uint32_t c, const SwCand &k, uint32_t t, bool late) {
 			// the finest partitions of the frame cover 2^(6 - pm) lanes each; lane p takes the sum of partition p
 			// (modulo 2^32, which is the reference's accumulator at these sizes, stream_encoder.c:3803)
-			uint32_t fr = t;
+			uint64_t fr = t;
 			if (pm < 6) {
+				if (RES == SW_SPLIT) {
+					// wide samples: the sum of several lanes' runs can pass 2^32, where the reference switches to a 64-bit
+					// accumulator by the partition's length and the sample width (stream_encoder.c:3803), not by the sum
 #pragma unroll
-				for (int j = 0; j < 6; j++)
-					if ((uint32_t)j < 6 - pm)
-						fr += (uint32_t)__shfl_xor((int)fr, 1 << j, 64);
-				fr = (uint32_t)__shfl((int)fr, (int)((ln << (6 - pm)) & 63u), 64);
+					for (int j = 0; j < 6; j++)
+						if ((uint32_t)j < 6 - pm)
+							fr += (uint64_t)__shfl_xor((unsigned long long)fr, 1 << j, 64);
+					fr = (uint64_t)__shfl((unsigned long long)fr, (int)((ln << (6 - pm)) & 63u), 64);
+					if (ilog2u(bsf >> pm) + sbps < 32)
+						fr &= 0xffffffffull;
+				} else {
+					uint32_t f32 = t;
+#pragma unroll
+					for (int j = 0; j < 6; j++)
+						if ((uint32_t)j < 6 - pm)
+							f32 += (uint32_t)__shfl_xor((int)f32, 1 << j, 64);
+					fr = (uint32_t)__shfl((int)f32, (int)((ln << (6 - pm)) & 63u), 64);
+				}
 				if (ln >= (1u << pm))
 					fr = 0;
 			}
@@ -462,20 +597,53 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		};
 
 		bool any_late = false;
+		SwRaw ahead;
+		if constexpr (RES == SW_SPLIT)
+			fetch(5, ahead);
 #pragma nounroll
 		for (uint32_t c = 0; c < total_cands; c++) {
 			SwCand k;
-			if (!candidate(c, k))
+			bool takes_part;
+			if constexpr (RES == SW_SPLIT) {
+				const SwRaw mine = ahead;
+				if (c >= 5)
+					fetch(c + 1, ahead);
+				takes_part = candidate(c, k, &mine);
+			} else
+				takes_part = candidate(c, k);
+			if (!takes_part)
 				continue;
-			if (!fa_fold_exact(k.sumq, k.shift, fold_bps)) {
+			SwFold fold;
+			if (RES == SW_SPLIT)
+				fold = sw_split_fold(k.sumq, k.shift, sbps, k.mode == 2u);
+			if (RES == SW_SPLIT ? !fold.exact : !fa_fold_exact(k.sumq, k.shift, fold_bps)) {
 				any_late = true;   // the folded chain could leave 32 bits: done exactly, below
 				continue;
 			}
 			const uint32_t order = k.order, shift = k.shift;
-			const uint32_t Bc = c31 >> shift;
+			const uint32_t Bc = c31 >> (RES == SW_SPLIT ? fold.sc : shift);
 			uint32_t t = 0;
 			uint32_t x[16];
-			if (RES == SW_DOT2) {
+			if constexpr (RES == SW_SPLIT) {
+				int32_t qf[SW_NQF];
+				qf[0] = sw_pack16(-(int32_t)(1u << shift), k.q[0]);
+#pragma unroll
+				for (int jj = 1; jj < SW_NQF; jj++)
+					qf[jj] = sw_pack16(k.q[2 * jj - 1], 2 * jj < SW_HIST ? k.q[2 * jj] : 0);
+				uint32_t a0v = fold.a0;
+				asm volatile("" : "+v"(a0v));
+				sw_negres_split<0>(w, wl, qf, order, fold, a0v, x);
+				t = sw_add_abs<0>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_split<16>(w, wl, qf, order, fold, a0v, x);
+				t = sw_add_abs<16>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_split<32>(w, wl, qf, order, fold, a0v, x);
+				t = sw_add_abs<32>(x, Bc, order, lane0, partial, nv0, t);
+				SW_FENCE();
+				sw_negres_split<48>(w, wl, qf, order, fold, a0v, x);
+				t = sw_add_abs<48>(x, Bc, order, lane0, partial, nv0, t);
+			} else if constexpr (RES == SW_DOT2) {
 				// c[0] = -2^shift, c[m] = q[m - 1], two to a word
 				int32_t qf[SW_NQF];
 				qf[0] = sw_pack16(-(int32_t)(1u << shift), k.q[0]);
@@ -512,7 +680,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 #pragma nounroll
 			for (uint32_t c = 0; c < total_cands; c++) {
 				SwCand k;
-				if (!candidate(c, k) || fa_fold_exact(k.sumq, k.shift, fold_bps))
+				if (!candidate(c, k) || (RES == SW_SPLIT ? sw_split_fold(k.sumq, k.shift, sbps, k.mode == 2u).exact : fa_fold_exact(k.sumq, k.shift, fold_bps)))
 					continue;
 				const uint32_t t = sw_lane_sum_exact(pcm, P.channels, B.sample_bytes, B.pairs, frame_start, s, wasted, ln, k.q, k.order, (int)k.shift, k.mode != 2u, bsf);
 				consider(c, k, t, true);
@@ -560,6 +728,27 @@ bool fa_search_wave_eligible(const FaEncParams &P)
 		return false;
 	// the reference's 32-bit partition sums (stream_encoder.c:3803) at every partition order this block can use
 	return 12 + P.bps + (P.do_ms ? 1u : 0u) < 32;
+}
+
+// Streams wider than that (20 to 24 bits, whose candidates mostly need the reference's 64-bit sums) take the same
+// kernel in its split-sample form, two waves per SIMD; their partition sums are put together in 64 bits where the
+// reference's accumulator is 64 bits wide.  Not with the search over coefficient precisions: with 137 candidates
+// per subframe what a candidate costs besides its residuals (fetching it, pricing it: lane exchanges and scalar
+// reads whose latency two waves per SIMD do not hide) decides, and the workgroup form, which prices two candidates
+// per step at three waves per SIMD, is the faster one there (150 s of 24-bit / 96 kHz stereo at -8 -e -p: 4.53 ms
+// against 5.64; eight channels of 24-bit / 192 kHz at -8, 17 candidates: 1.08 ms against 0.82).
+bool fa_search_wave_split_eligible(const FaEncParams &P)
+{
+	if (P.blocksize != SW_N * 64 || P.max_po > 6 || P.max_lpc_order > SW_HIST || fa_search_wave_eligible(P) || P.prec_search)
+		return false;
+	return P.bps + (P.do_ms ? 1u : 0u) <= 25;
+}
+
+void fa_launch_search_wave_split(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
+                                 const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, hipStream_t st)
+{
+	const dim3 grid((B.nframes + 7) / 8 * 8 * nsel);
+	hipLaunchKernelGGL((k_search_wave<SW_SPLIT, false>), grid, dim3(64), 0, st, P, B, pcm, stats, cands, coefs, plans, sig_list, nsel);
 }
 
 // wide_list: those of the signals that can be wider than 16 bits (the rest never need the second launch)

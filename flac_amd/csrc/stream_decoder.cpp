@@ -1322,15 +1322,19 @@ bool next_frame(FLAC__StreamDecoder *d, bool *got_a_frame, bool do_full_decode)
 // Seeking (what seek_to_absolute_sample_, stream_decoder.c:2973, does for the reference), built on
 // what this decoder has anyway: whatever stretch of the stream is read next is decoded as a window
 // of whole frames whose sample numbers come back in the frame table, and a frame seen while
-// is_seeking is set is inspected by write_audio_frame instead of delivered.  So the hunt is:
-//   1. aim - at the last seek point at or before the target when there is a seek table, else at
-//      (bytes per sample of this stream) x target, a little in front;
-//   2. look - read from there; every frame that ends at or before the target is walked past, the
-//      frame that holds the target ends the hunt (its tail is delivered);
-//   3. correct - if the first frame seen starts beyond the target, aim again further back by the
-//      overshoot (in samples, times the density) plus a margin that doubles each time; if the target
-//      is many frames ahead, aim again further on instead of walking there.
-// The density is measured (stream length / total samples) where STREAMINFO has the totals.
+// is_seeking is set is inspected by write_audio_frame instead of delivered.  Like the reference the
+// hunt keeps a bracket: [lo_pos, lo_sample] is a place where reading finds a frame that starts at or
+// before the target, [hi_pos, hi_sample] one where it finds a frame beyond it (or the end of the
+// stream); the seek table and STREAMINFO give the first bracket, every probe narrows it, and no
+// probe is ever aimed outside it, so the hunt cannot run in circles whatever the local density.
+//   1. aim - inside the bracket, by interpolation between its ends (a little in front of where the
+//      target would be), every third time by bisection so that a stream whose density changes
+//      abruptly (silence, then noise) still closes the bracket geometrically;
+//   2. look - read from there; every frame that ends at or before the target is walked past and
+//      raises the lower end, the frame that holds the target ends the hunt (its tail is delivered);
+//      when the target is still many frames ahead, aim again instead of walking there;
+//   3. overshoot - the first frame seen starts beyond the target: this place becomes the upper end;
+//   4. once the bracket is a few dozen frames wide, start at its lower end and only walk.
 bool seek_to_absolute_sample(FLAC__StreamDecoder *d, FLAC__uint64 stream_length, FLAC__uint64 target)
 {
 	FLAC__StreamDecoderPrivate *q = d->private_;
@@ -1348,41 +1352,76 @@ bool seek_to_absolute_sample(FLAC__StreamDecoder *d, FLAC__uint64 stream_length,
 	if (stream_length <= origin)
 		return fail();
 
-	double density;  // bytes of stream per sample
+	double density;  // bytes of stream per sample, for the first aim and where the bracket has no upper sample number
 	if (total > 0)
 		density = (double)(stream_length - origin) / (double)total;
 	else if (si.max_framesize > 0)
 		density = 0.5 * ((double)si.min_framesize + (double)si.max_framesize) / (double)block;
 	else
 		density = (double)channels * (double)bps / 8.0;
-	const double frame_bytes = density * (double)block + 64.0;
+	// the most bytes a frame can take: what STREAMINFO says, else every sample verbatim
+	const double frame_bytes = (si.max_framesize > 0 ? (double)si.max_framesize : (double)channels * ((double)bps + 1.0) / 8.0 * (double)block + 32.0) + 64.0;
 
-	// 1. aim
-	double aim = (double)origin + density * (double)target - 1.5 * frame_bytes;
+	// the first bracket: the whole stream, narrowed by the seek points either side of the target
+	FLAC__uint64 lo_pos = origin, lo_sample = 0;
+	FLAC__uint64 hi_pos = stream_length, hi_sample = total;  // hi_sample 0: not known
 	if (q->has_seek_table) {
 		const FLAC__StreamMetadata_SeekTable &st = q->seek_table.data.seek_table;
-		const FLAC__StreamMetadata_SeekPoint *best = 0;
 		for (unsigned i = 0; i < st.num_points; i++) {
 			const FLAC__StreamMetadata_SeekPoint &pt = st.points[i];
 			if (pt.sample_number == FLAC__STREAM_METADATA_SEEKPOINT_PLACEHOLDER || pt.frame_samples == 0)
 				continue;
 			if (total > 0 && pt.sample_number >= total)
 				continue;
-			if (pt.sample_number <= target && origin + pt.stream_offset < stream_length && (!best || pt.sample_number > best->sample_number))
-				best = &pt;
+			const FLAC__uint64 at = origin + pt.stream_offset;
+			if (at >= stream_length)
+				continue;
+			if (pt.sample_number <= target) {
+				if (pt.sample_number >= lo_sample && at >= lo_pos) {
+					lo_sample = pt.sample_number;
+					lo_pos = at;
+				}
+			} else if (at < hi_pos && at > lo_pos) {
+				hi_pos = at;
+				hi_sample = pt.sample_number;
+			}
 		}
-		if (best)
-			aim = (double)(origin + best->stream_offset);  // a frame starts exactly here; a sparse table is made up for by the jump in step 3
+		if (hi_pos <= lo_pos) {  // a table that contradicts itself is not used
+			lo_pos = origin;
+			lo_sample = 0;
+			hi_pos = stream_length;
+			hi_sample = total;
+		}
 	}
 
 	q->target_sample = target;
-	double margin = frame_bytes;
-	FLAC__uint64 pos = 0;
-	for (unsigned attempt = 0; attempt < 64; attempt++) {
-		FLAC__uint64 want = aim <= (double)origin ? origin : (FLAC__uint64)aim;
-		if (want >= stream_length)
-			want = stream_length - 1;
-		pos = want;
+	const double near = 48.0 * frame_bytes;  // a bracket this narrow is walked through
+	bool walk_only = false;
+	for (unsigned attempt = 0; attempt < 96; attempt++) {
+		// 1. aim
+		double aim;
+		if (walk_only || (double)(hi_pos - lo_pos) <= near) {
+			// 4. (the lower end is always a place where a frame starts: the first frame, a seek point, or the byte
+			// behind a frame that was walked past)
+			aim = (double)lo_pos;
+			walk_only = true;
+		} else if (attempt % 3 == 2)
+			aim = 0.5 * ((double)lo_pos + (double)hi_pos);
+		else {
+			double est;
+			if (hi_sample > lo_sample && target < hi_sample)
+				est = (double)(target - lo_sample) / (double)(hi_sample - lo_sample) * (double)(hi_pos - lo_pos);
+			else
+				est = (double)(target - lo_sample) * density;
+			aim = (double)lo_pos + est - 1.5 * frame_bytes;
+			if (aim >= (double)hi_pos - frame_bytes)
+				aim = 0.5 * ((double)lo_pos + (double)hi_pos);
+		}
+		if (aim < (double)lo_pos)
+			aim = (double)lo_pos;
+		FLAC__uint64 pos = (FLAC__uint64)aim;
+		if (pos >= stream_length)
+			pos = stream_length - 1;
 		if (q->seek_callback(d, pos, q->client_data) != FLAC__STREAM_DECODER_SEEK_STATUS_OK)
 			return fail();
 		if (!FLAC__stream_decoder_flush(d))
@@ -1397,37 +1436,56 @@ bool seek_to_absolute_sample(FLAC__StreamDecoder *d, FLAC__uint64 stream_length,
 			if (!q->is_seeking)
 				return true;  // write_audio_frame found the target in this frame and delivered its tail
 			if (p->state == FLAC__STREAM_DECODER_END_OF_STREAM || q->samples_decoded == 0) {
-				// ran off the end without a frame: look from further back
-				if (pos == origin)
+				// ran off the end without meeting the target: nothing from here on holds it
+				if (!first_here || pos <= origin)
 					return fail();
-				aim = (double)pos - margin;
-				margin *= 2.0;
+				if (pos <= lo_pos) {
+					// a lower end that came from a seek point that is not true: fall back on the stream's start
+					lo_pos = origin;
+					lo_sample = 0;
+					walk_only = false;
+				}
+				hi_pos = pos;
 				break;
 			}
 			const FLAC__uint64 first = q->last_frame.header.number.sample_number;
 			const FLAC__uint64 end = first + q->last_frame.header.blocksize;
 			if (target < first) {
 				// 3. overshoot
-				if (pos == origin || !first_here)
+				if (!first_here || pos <= origin)
 					return fail();  // the stream's frames do not hold the target
-				aim = (double)pos - (double)(first - target) * density - margin;
-				margin *= 2.0;
+				if (pos <= lo_pos) {
+					lo_pos = origin;
+					lo_sample = 0;
+					walk_only = false;
+				}
+				hi_pos = pos;
+				hi_sample = first;
 				break;
 			}
 			first_here = false;
-			// the target lies ahead (end <= target): walk on, or jump when it is far
-			const double ahead = (double)(target - end) * density;
-			if (ahead > 48.0 * frame_bytes) {
-				FLAC__uint64 here;
-				if (!FLAC__stream_decoder_get_decode_position(d, &here))
-					return fail();
-				const double jump = (double)here + ahead - 4.0 * frame_bytes;
-				if (jump > (double)here + 8.0 * frame_bytes) {
-					aim = jump;
-					break;
-				}
+			// the target lies ahead (end <= target): the next frame starts here
+			FLAC__uint64 here;
+			if (!FLAC__stream_decoder_get_decode_position(d, &here)) {
+				walk_only = true;  // no position to aim from: walk on from here
+				continue;
 			}
+			if (here > lo_pos && here < hi_pos) {
+				lo_pos = here;
+				lo_sample = end;
+			}
+			if (walk_only)
+				continue;
+			double ahead;
+			if (hi_sample > end && target < hi_sample && hi_pos > here)
+				ahead = (double)(target - end) / (double)(hi_sample - end) * (double)(hi_pos - here);
+			else
+				ahead = (double)(target - end) * density;
+			if (ahead > near && (double)(hi_pos - here) > near)
+				break;  // aim again, inside the narrowed bracket
 		}
+		if (hi_pos <= lo_pos)
+			return fail();
 	}
 	return fail();
 }

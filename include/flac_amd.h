@@ -127,8 +127,14 @@ int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm, uint64_t 
  *   status_dev   device word that receives the error bits flacamd_encoder_status would report
  *                (0 = none, bit 0 a frame outgrew its slot, bit 1 out_dev too small); may be NULL
  * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams,
- * two threads) race; calls on different GPUs do not.  The first call on a device, and any call that
- * changes blocksize or apodizations, uploads tables with a synchronous copy. */
+ * two threads) race (the library serialises only its own bookkeeping, the caller serialises the
+ * calls); calls on different GPUs do not.  Three things in it are not legal while a stream is being
+ * captured into a HIP graph, so a caller that captures does them beforehand or avoids them: the first
+ * call on a device uploads the CRC tables (hipMemcpyToSymbol) and any call that changes blocksize or
+ * apodizations waits for the device and uploads window tables with a synchronous copy - make one
+ * warm-up call with the same settings outside the capture; and a call with loose mid/side settings
+ * (-1, -4) and loose_state != NULL copies that word back and waits for the stream - pass NULL and
+ * cut batches at multiples of the loose mid/side period instead. */
 #define FLACAMD_STATIC_SCRATCH_BYTES (32u << 20)
 int flacamd_encode_frames_static(const flacamd_encode_params *p, int device, const void *pcm_dev,
                                  uint32_t sample_bytes, uint64_t wide_samples, uint32_t first_frame,

@@ -1,13 +1,16 @@
 """GPU tests at the sizes of the benchmark configurations that are not the bench line itself:
 `flac -5` on ten minutes of 16-bit stereo, `-8 -e -p` on 24-bit/96 kHz stereo, eight channels of
-24-bit/192 kHz, and one GPU's share of the ten-thousand-stream batch decode.
+24-bit/192 kHz, and one GPU's share of the ten-thousand-stream batch decode - each on the signal the
+benchmark uses for it (flac_amd.workloads: synth_pcm, seed 1234 + 1000 x stream).
 
 At these sizes the CPU restatement cannot check every byte in seconds, so each case is held to
 properties that do not depend on size: the decoder gives back exactly the samples that went in,
 every frame is accounted for, the frame sizes add up, and a leading stretch of the stream is
 byte-identical to what the oracle (tests/oracle_lib.py) produces for the same samples.  The
 ten-minute `-5` case is short enough on the CPU to be compared whole against the reference
-library when that has been built (oracle/_ref)."""
+library when that has been built (oracle/_ref); tests/test_gpu_reference_accepts.py does the same
+for the other configurations.  `synth` below is a second, cheaper signal (tones, a sweep and
+uniform noise) that the decoder probes and a few tests with a history of their own keep using."""
 import os
 
 import numpy as np
@@ -109,8 +112,9 @@ def test_level5_ten_minutes_against_the_reference_library():
     """configs[0]: `flac -5`, 16-bit/44.1 kHz stereo, ten minutes: every frame byte equals the
     reference library's, and the stream decodes back to the input."""
     import flac_amd
-    pcm = synth(5, 44100 * 600, 2, 16, 44100)
-    p = flac_amd.preset(5, 2, 16, 44100)
+    from flac_amd import workloads as W
+    pcm = W.pcm("C1")
+    p = W.params("C1", flac_amd)
     frames_dev, szs = check_round_trip(p, pcm, 2, oracle_frames=40)
     if not os.path.exists(REF_LIB):
         pytest.skip("reference library not built: compared with the oracle on the leading frames only")
@@ -124,19 +128,21 @@ def test_level5_ten_minutes_against_the_reference_library():
 def test_exhaustive_precision_search_24bit_96k():
     """configs[2]: `flac -8 -e -p` on 24-bit/96 kHz stereo, ten minutes (the last block is short)."""
     import flac_amd
-    wide = 96000 * 600
-    pcm = synth(24, wide, 2, 24, 96000)
-    p = flac_amd.preset(8, 2, 24, 96000, do_exhaustive_model_search=1, do_qlp_coeff_prec_search=1)
-    assert wide % p.blocksize != 0
+    from flac_amd import workloads as W
+    pcm = W.pcm("C3")
+    wide = pcm.shape[0]
+    p = W.params("C3", flac_amd)
+    assert wide == 96000 * 600 and wide % p.blocksize != 0 and p.do_qlp_coeff_prec_search and p.do_exhaustive_model_search
     check_round_trip(p, pcm, 4, oracle_frames=6)
 
 
 def test_eight_channels_24bit_192k():
     """configs[3]: eight independent 24-bit/192 kHz channels, one minute, `flac -8`."""
     import flac_amd
-    pcm = synth(8, 192000 * 60, 8, 24, 192000)
-    p = flac_amd.preset(8, 8, 24, 192000)
-    assert p.do_mid_side_stereo == 0 or p.channels != 2
+    from flac_amd import workloads as W
+    pcm = W.pcm("C4")
+    p = W.params("C4", flac_amd)
+    assert pcm.shape == (192000 * 60, 8)
     check_round_trip(p, pcm, 4, oracle_frames=6)
 
 
@@ -145,12 +151,14 @@ def test_batch_decode_one_gpus_share_of_ten_thousand_streams():
     order) decoded in one call; every stream must come back as the PCM it was made from."""
     import flac_amd
     import torch
+    from flac_amd import workloads as W
     rate, seconds, distinct, copies = 44100, 5, 25, 50
     wide = rate * seconds
-    p = flac_amd.preset(8, 2, 16, rate)
+    p = W.params("C5", flac_amd)
     sources, encoded = [], []
     for i in range(distinct):
-        pcm = synth(100 + i, wide, 2, 16, rate)
+        pcm = W.pcm("C5", stream_id=i)
+        assert pcm.shape == (wide, 2)
         dev, out, sizes, offs, nframes = gpu_encode(p, pcm, 2)
         total = int(offs[nframes].item())
         sources.append(dev)

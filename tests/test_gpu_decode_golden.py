@@ -188,23 +188,6 @@ def test_damaged_frames_leave_their_neighbours_alone(channels, bps, rate, bs, le
         dec.close()
 
 
-def test_cooperative_form_decodes_every_golden_stream(monkeypatch):
-    """FLAC_AMD_DEC_MODE=coop selects the wave-per-frame form of the frame decoder (dec_coop.hip), which is not the
-    default: it must give back every golden stream exactly, like the lane-per-frame form the other tests run."""
-    import flac_amd
-    monkeypatch.setenv("FLAC_AMD_DEC_MODE", "coop")
-    for case in CASES:
-        pcm, _meta, frames = golden_util.load_case(case)
-        blob = b"".join(frames)
-        dec = flac_amd.Decoder(case["channels"], case["bps"], blocksize_of(case), device=0, max_input_bytes=len(blob) + 64, max_frames=len(frames) + 8)
-        try:
-            got, nfr, nwide, bad = dec.decode_host(blob, [(0, len(blob), 0, pcm.shape[0])], pcm.shape[0], out_sample_bytes=4)
-        finally:
-            dec.close()
-        assert (nfr, nwide, bad) == (len(frames), pcm.shape[0], 0), case["name"]
-        assert np.array_equal(got, pcm), case["name"]
-
-
 def test_lane_per_frame_form_decodes_every_golden_stream(monkeypatch):
     """Small batches of streams with two or more channels are decoded in the split form (a walk that finds where every
     subframe starts, then a lane per subframe), which is what the other tests therefore run; FLAC_AMD_DEC_MODE=lane keeps

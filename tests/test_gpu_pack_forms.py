@@ -99,3 +99,20 @@ def test_frame_form_against_the_oracle():
             got = encode(p, pcm, "frame")
             want, _ = O.encode_frames(op, pcm)
             assert got == list(want), (level, name)
+
+
+@pytest.mark.parametrize("bs", [1024, 256])
+def test_both_forms_against_the_oracle_at_smaller_block_sizes(bs):
+    """Blocks below 4096 samples: both writers against the CPU restatement of the reference, so that something the two
+    forms share (the residual recomputation, the Rice writer's pieces) cannot be wrong in both unnoticed."""
+    import flac_amd
+    import oracle_lib as O
+    sigs = signals(16, 2)
+    for sname, level, over in (("level8", 8, {}), ("level1_loose", 1, {}), ("level8_po8", 8, {"max_residual_partition_order": 8})):
+        p = flac_amd.preset(level, 2, 16, 44100, bs, **over)
+        op = O.preset(level, 2, 16, 44100, bs, **over)
+        for name, pcm in sigs.items():
+            pcm = pcm[:bs * 4 + bs // 3]
+            want, _ = O.encode_frames(op, pcm)
+            for form in ("generic", "frame"):
+                assert encode(p, pcm, form) == list(want), (sname, name, bs, form)

@@ -103,3 +103,19 @@ def test_wave_form_against_the_oracle():
         got = encode(p, pcm, "wave")
         want, _ = O.encode_frames(op, pcm)
         assert got == list(want), name
+
+
+@pytest.mark.parametrize("bps,channels", [(16, 1), (8, 2), (12, 2), (16, 3), (24, 2), (24, 3), (20, 1)])
+def test_both_forms_against_the_oracle_on_other_shapes(bps, channels):
+    """Mono, three channels (no mid/side), 8-, 12-, 20- and 24-bit samples (the wide residual arithmetic): whichever forms
+    take the shape are held against the CPU restatement of the reference, not only against each other."""
+    import flac_amd
+    import oracle_lib as O
+    sigs = signals(bps, channels)
+    for sname, level, over in (("level8", 8, {}), ("level8_p", 8, {"do_qlp_coeff_prec_search": 1}), ("level5", 5, {})):
+        p = flac_amd.preset(level, channels, bps, 44100, BS, **over)
+        op = O.preset(level, channels, bps, 44100, BS, **over)
+        for name, pcm in sigs.items():
+            want, _ = O.encode_frames(op, pcm)
+            for form in ("generic", "wave"):
+                assert encode(p, pcm, form) == list(want), (sname, name, bps, channels, form)

@@ -296,3 +296,38 @@ def test_random_seeks(lib, variant):
         assert sd.errors == []
     finally:
         sd.close()
+
+
+@pytest.mark.parametrize("order", ["silence_then_noise", "noise_then_silence"])
+@pytest.mark.parametrize("known_total", [True, False])
+def test_seeks_in_a_stream_of_very_uneven_density(lib, order, known_total):
+    """Half of the stream is digital silence (a few bytes per frame), the other half full-scale noise (verbatim frames),
+    no seek table: a place worked out from the average density is wrong by almost half the stream, so the hunt has to
+    bracket the target as the reference's does (stream_decoder.c:2973ff) instead of aiming from one global figure."""
+    rng = np.random.default_rng(5)
+    half = 44100 * 12
+    noise = rng.integers(-30000, 30000, size=(half, 2)).astype(np.int32)
+    quiet = np.zeros((half, 2), dtype=np.int32)
+    pcm = np.concatenate([quiet, noise] if order == "silence_then_noise" else [noise, quiet])
+    n = pcm.shape[0]
+    meta, frames, ok, _w = L.encode(lib, pcm, 16, 44100, level=5, chunk=1 << 18, seekable=True, total_samples_estimate=n)
+    assert ok
+    if not known_total:
+        m = bytearray(meta)
+        m[8 + 13] &= 0xf0
+        m[8 + 14:8 + 18] = bytes(4)
+        meta = bytes(m)
+    stream = meta + b"".join(frames)
+    sd = L.StreamDecoder(lib, stream, seekable=True)
+    try:
+        assert sd.init_status == 0
+        targets = [int(t) for t in rng.integers(0, n, size=24)] + [half - 1, half, half + 1, 5, n - 5, half // 2, half + half // 2]
+        for target in targets:
+            sd.blocks.clear()
+            assert sd.call("seek_absolute", C.c_uint64(target)), "seek to %d" % target
+            first, blk = sd.blocks[0]
+            assert first == target
+            assert np.array_equal(blk, pcm[target:target + blk.shape[0]])
+        assert sd.errors == []
+    finally:
+        sd.close()

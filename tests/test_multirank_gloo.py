@@ -155,3 +155,83 @@ def test_deal_streams_round_robin():
             assert max(len(d) for d in dealt) - min(len(d) for d in dealt) <= 1
     with pytest.raises(ValueError):
         shard.deal_streams(4, 2, 2)
+
+
+def plan_worker(rank, world, port, seconds, out_dir):
+    """What `bench.py --config C3 --gpus 2` and `--config C5 --gpus 2` do per rank, with the CPU oracle in the
+    HIP library's place: the plans come from flac_amd.workloads.plan, the same call bench.py makes."""
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    from flac_amd import shard
+    from flac_amd import workloads as W
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # C3, strong scaling: ONE stream cut into contiguous frame ranges
+        cfg = W.CONFIGS["C3"]
+        p = O.preset(cfg["level"], cfg["channels"], cfg["bps"], cfg["rate"], **cfg["over"])
+        pl = W.plan("C3", "strong", world, rank, p.blocksize, seconds=seconds)
+        pcm = W.shard_pcm("C3", pl)
+        assert pcm.shape[0] == pl["wide"]
+        frames, _ = O.encode_frames(p, pcm, first_frame=pl["first_frame"])
+        whole = shard.gather_stream(b"".join(frames))
+        if rank == 0:
+            with open(os.path.join(out_dir, "c3.bin"), "wb") as f:
+                f.write(whole)
+        # C3, weak scaling: the stream is world times as long, rank r's range is signal r
+        plw = W.plan("C3", "weak", world, rank, p.blocksize, seconds=seconds)
+        assert plw["first_frame"] == rank * -(-W.wide_samples("C3", seconds) // p.blocksize) and plw["signal"] == rank
+        assert plw["is_last"] == (rank == world - 1)
+        # C5: the batch dealt round-robin, nothing exchanged
+        c5 = W.CONFIGS["C5"]
+        p5 = O.preset(c5["level"], c5["channels"], c5["bps"], c5["rate"])
+        pl5 = W.plan("C5", "strong", world, rank, p5.blocksize, seconds=0.25, streams=7)
+        assert pl5["mine"] == shard.deal_streams(7, world, rank) and pl5["job_samples"] == 7 * pl5["stream_wide"] * 2
+        for k, i in enumerate(pl5["mine"]):
+            src = W.pcm("C5", stream_id=i % pl5["distinct"], wide=pl5["stream_wide"], stream_wide=pl5["stream_wide"])
+            fr, _ = O.encode_frames(p5, src)
+            n, got, _nf = O.decode_frames(b"".join(fr), 2, 16, c5["rate"], src.shape[0])
+            assert n == src.shape[0] and np.array_equal(got, src)
+            np.save(os.path.join(out_dir, "c5_r%d_%d.npy" % (rank, k)), got)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_bench_plans_for_c3_and_c5(tmp_path):
+    import torch.multiprocessing as mp
+
+    import oracle_lib as O
+    from flac_amd import shard
+    from flac_amd import workloads as W
+    seconds = 0.2   # 19 200 wide samples of 24-bit / 96 kHz: five blocks, the last one short
+    mp.spawn(plan_worker, args=(2, free_port(), seconds, str(tmp_path)), nprocs=2, join=True)
+    cfg = W.CONFIGS["C3"]
+    p = O.preset(cfg["level"], cfg["channels"], cfg["bps"], cfg["rate"], **cfg["over"])
+    want, _ = O.encode_frames(p, W.pcm("C3", seconds=seconds, stream_wide=W.wide_samples("C3", seconds)))
+    assert len(want) == 5 and open(str(tmp_path / "c3.bin"), "rb").read() == b"".join(want)
+    per_rank = [[np.load(str(tmp_path / ("c5_r%d_%d.npy" % (r, k)))) for k in range(len(shard.deal_streams(7, 2, r)))] for r in range(2)]
+    for i, got in enumerate(shard.undeal(per_rank)):
+        assert np.array_equal(got, W.pcm("C5", stream_id=i, wide=got.shape[0], stream_wide=got.shape[0]))
+
+
+def test_bench_plans_cover_the_job():
+    from flac_amd import workloads as W
+    for name, bs in (("C2", 4096), ("C3", 4096), ("C4", 4096)):
+        for scaling in ("weak", "strong"):
+            for world in (1, 2, 4, 8):
+                plans = [W.plan(name, scaling, world, r, bs) for r in range(world)]
+                pos = 0
+                for pl in plans:
+                    assert pl["first_sample"] == pos and pl["first_frame"] * bs == pos
+                    pos += pl["wide"]
+                assert pos == plans[0]["stream_wide"] and plans[-1]["is_last"] and not any(pl["is_last"] for pl in plans[:-1])
+                assert plans[0]["job_samples"] == pos * W.CONFIGS[name]["channels"]
+                one = W.wide_samples(name)
+                assert pos == one if scaling == "strong" else pos >= world * (one - bs)
+    for world in (1, 2, 8):
+        mine = [W.plan("C5", "strong", world, r, 4096)["mine"] for r in range(world)]
+        assert sorted(i for m in mine for i in m) == list(range(10000))

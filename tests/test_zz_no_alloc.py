@@ -68,6 +68,15 @@ def test_static_entry_point_matches_the_handle_based_one_twice_in_a_row():
     assert a > b > 0 and c > 0
 
 
+def test_window_tables_survive_a_call_without_windows():
+    # -8, then -0 at blocksize 1152 (no LPC, so no window table, and smaller buffers), then -8 again: the window table
+    # kept from the first call must not have been overwritten by the second call's buffers
+    a = encode_both_ways(8, 2, 16, 44100, 4096 * 20 + 5, seed=21)
+    b = encode_both_ways(0, 2, 16, 44100, 1152 * 300, seed=22)
+    c = encode_both_ways(8, 2, 16, 44100, 4096 * 20 + 5, seed=21)
+    assert a == c and b > 0
+
+
 def test_static_entry_point_refuses_what_does_not_fit():
     import torch
 

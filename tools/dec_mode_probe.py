@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Batch decode time of the decoder's forms against the shape of the batch.  A variant is a FLAC_AMD_DEC_MODE value
-(lane / split / coop), optionally followed by frames per wave and frames per wave of the split form's walk:
+(lane / split), optionally followed by frames per wave and frames per wave of the split form's walk:
 usage: python tools/dec_mode_probe.py lane split split,8 split,16,4 ..."""
 import os
 import sys
@@ -14,7 +14,7 @@ import torch
 import flac_amd
 from test_gpu_configs_full_size import synth
 
-variants = sys.argv[1:] or ["lane", "split", "coop"]
+variants = sys.argv[1:] or ["lane", "split"]
 dev = torch.device("cuda", 0)
 for channels, bps, rate, counts in ((2, 16, 44100, (256, 1024, 4096, 6460, 16384)), (2, 24, 96000, (14063,)), (8, 24, 192000, (256, 2813))):
     p = flac_amd.preset(8, channels, bps, rate)
