@@ -245,7 +245,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.number_scale = d->number_scale;
 	P.lw = d->lw;
 	P.skip_lw = d->skip_lw;
-	P.pad = 0;
+	P.run = 16;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	const bool prof = d->profiling != 0;

@@ -11,6 +11,7 @@
 #define DEC_LANES 64
 
 __device__ __forceinline__ uint32_t d_ilog2(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ __forceinline__ uint32_t umin_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // the fixed predictors as filter coefficients (fixed.c:395)
 __constant__ static const int8_t c_fixed_q[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, {2, -1, 0, 0}, {3, -3, 1, 0}, {4, -6, 4, -1}};
@@ -28,8 +29,13 @@ __constant__ static const int8_t c_fixed_q[5][4] = {{0, 0, 0, 0}, {1, 0, 0, 0}, 
 // ---------------------------------------------------------------------------------------------
 #define DEC_MAXLW 16        // frames per wave at most, except for the largest batches (k_dec_frames<.., 32>)
 #define RING_CHUNK 64       // words per refill (one per lane of the wave)
-#define RING_WORDS 128      // words per lane in LDS: two chunks
-#define DEC_BLOCK 16        // samples decoded between refill / flush points
+#define RING_WORDS_MIN 128  // words per lane in LDS: two chunks (the instance with 32 frames per wave), or four (RING_WORDS_BIG)
+#define RING_WORDS_BIG 256
+#define DEC_BLOCK 16        // samples per unrolled block
+// samples decoded between refill / flush points where every lane has nothing but plain symbols ahead: as many as the
+// ring is sure to hold while refills are in flight (see pump_service), four blocks with the deep ring, two without
+#define DEC_RUN_BIG 64
+#define DEC_RUN_MIN 32
 
 struct BitRd {
 	const uint32_t *wg;  // the frame's first word in global memory (word index wbase of the input)
@@ -39,9 +45,10 @@ struct BitRd {
 	uint32_t rem;        // 0..31
 	uint32_t wrel;       // index, relative to wbase, of the word after nxt
 	uint32_t nrel;       // words from wbase to the end of the input (saturated)
-	uint32_t limit;      // words [0, limit) have been in the ring; the last RING_WORDS of them still are
+	uint32_t limit;      // words [0, limit) have been in the ring; the last rmask + 1 of them still are
+	uint32_t rmask;      // words per lane in the ring, minus one
 	uint32_t bend;       // first bit past the stream on the same scale (saturated)
-	const uint32_t *ring;  // this lane's RING_WORDS words of LDS
+	const uint32_t *ring;  // this lane's words of LDS
 	bool err;
 };
 
@@ -49,13 +56,13 @@ struct BitRd {
 // rem + 32 bits are still unread.
 __device__ __forceinline__ uint32_t br_pos(const BitRd &r) { return 32u * (r.wrel - 1u) - r.rem; }
 
-// The refill protocol keeps limit - RING_WORDS <= wrel, so one compare tells whether the ring has
+// The refill protocol keeps limit - (words in the ring) <= wrel, so one compare tells whether the ring has
 // the word; a lane that has outrun its ring reads global memory itself.
 __device__ __forceinline__ uint32_t br_fetch(BitRd &r)
 {
 	uint32_t v;
 	if (r.wrel < r.limit)
-		v = r.ring[r.wrel & (RING_WORDS - 1)];   // the ring holds the words already byte-swapped
+		v = r.ring[r.wrel & r.rmask];   // the ring holds the words already byte-swapped
 	else
 		v = __builtin_bswap32(r.wrel < r.nrel ? r.wg[r.wrel] : 0u);
 	r.wrel++;
@@ -130,13 +137,15 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 // k_dec_frames
 // ---------------------------------------------------------------------------------------------
 // MAXLW: the most frames a wave of this instance carries (the LDS it takes grows with it)
-template <int MAXLW>
+template <int MAXLW, int RINGW>
 struct DecLds {
 	static constexpr int maxlw = MAXLW;
+	static constexpr int ring_words = RINGW;
+	static constexpr int run = RINGW > RING_WORDS_MIN ? DEC_RUN_BIG : DEC_RUN_MIN;
 	int32_t q[FA_MAX_ORDER][MAXLW];          // predictor coefficients per lane
 	int32_t w[FA_MAX_ORDER][MAXLW];          // warm-up samples per lane
-	uint32_t ring[MAXLW][RING_WORDS];        // input words per lane
-	int32_t out[2 * DEC_BLOCK * MAXLW];      // a block of decoded samples, [sample][lane]; second half: spare
+	uint32_t ring[MAXLW][RINGW];             // input words per lane
+	int32_t out[run * MAXLW + 1];            // a run of decoded samples, [sample][lane]; the last word: for the lanes without a frame
 };
 
 // The wave-level input pump.  Up to four refills are in flight (one word per thread each); they are
@@ -146,7 +155,7 @@ struct DecLds {
 struct Pump {
 	uint32_t data[PUMP_SLOTS];
 	int lane[PUMP_SLOTS];      // whose ring the word goes to, -1 = slot free
-	uint32_t half[PUMP_SLOTS]; // which half of that ring
+	uint32_t half[PUMP_SLOTS]; // which chunk of that ring
 };
 
 // what a lane knows about its current subframe once the subframe header is parsed
@@ -161,8 +170,10 @@ struct SubHdr {
 
 __device__ __forceinline__ uint32_t wave_value(uint32_t v, int lane_id) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane_id); }
 
-// Service point (every lane of the wave takes part): land the refills in flight, then start
-// refills for up to two lanes that have moved into the newest chunk of their ring.
+// Service point (every lane of the wave takes part): land the refills in flight, then start refills for up to four
+// lanes whose oldest chunk is read up.  (With two chunks per ring a lane can ask only once it is inside the newest
+// one, and the lanes of a wave, which start together and read at similar rates, all ask at about the same time: the
+// last ones served are then nearly dry.  With four chunks there are two chunks of slack.)
 template <typename LDS>
 __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_t tid, bool live, uint64_t nwords)
 {
@@ -177,7 +188,7 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_
 		}
 	}
 	// a lane wants the next chunk once its read position is inside the newest one
-	const bool want = live && !r.err && r.wrel + RING_CHUNK >= r.limit && r.limit < r.nrel;
+	const bool want = live && !r.err && r.wrel + (LDS::ring_words - RING_CHUNK) >= r.limit && r.limit < r.nrel;
 	uint64_t m = __ballot(want);
 #pragma unroll
 	for (int sl = 0; sl < NSL; sl++) {
@@ -189,7 +200,7 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_
 			const uint64_t at = wb + lim + tid;
 			pm.data[sl] = at < nwords ? (r.wg - r.wbase)[at] : 0u;
 			pm.lane[sl] = ln;
-			pm.half[sl] = (lim / RING_CHUNK) & 1;
+			pm.half[sl] = (lim / RING_CHUNK) & (LDS::ring_words / RING_CHUNK - 1);
 		}
 	}
 }
@@ -216,12 +227,8 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_
 // values, nothing is predicted or stored (M is 0).
 template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
-                                               uint32_t bsf, bool live, uint64_t nwords)
+                                               uint32_t bsf, bool live, uint64_t nwords, uint32_t run_len)
 {
-	// (What the instances compute their addresses from is made opaque on the way in.  The single-pass kernel's loop
-	// over the channels holds all eighteen instances, and the compiler otherwise moves the address arithmetic of each
-	// in front of that loop, where it stays live throughout: several hundred registers.)
-	asm volatile("" : "+v"(tid), "+s"(LW));
 	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
 	// are switched on at the first residual; lanes without a predictor keep zeros
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
@@ -240,8 +247,9 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	uint32_t seg_end = 0, fast_end = 0;
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
-	// lanes that carry no frame write their block samples to a spare area
-	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[DEC_BLOCK * LDS::maxlw];
+	// sample s of the run in hand goes to slot[s * sstride]; lanes that carry no frame all write to one spare word
+	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[LDS::run * LDS::maxlw];
+	const uint32_t sstride = tid < LW ? LW : 0u;
 	// the partition parameter(s) due at sample i (stream_decoder.c:2741-2767); the predictor is switched on with the first
 	auto read_part = [&](uint32_t i) __attribute__((always_inline)) {
 		if (M > 0 && i == h.order) {
@@ -306,15 +314,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		}
 		return v;
 	};
-	for (uint32_t i0 = 0; i0 < bs_w; i0 += DEC_BLOCK) {
+	for (uint32_t i0 = 0; i0 < bs_w;) {
 		pump_service(pm, r, L, tid, live, nwords);
-		if (br_pos(r) > r.bend) {
-			r.err = true;
-			work_end = 0;
-			seg_end = 0;
-		}
-		// A partition that starts with the block (partitions of 16 k samples always do) has its parameter read here, so
-		// that the block itself is nothing but symbols.
+		// A partition that starts here (partitions of 16 k samples always start with a block) has its parameter read
+		// now, so that the block itself is nothing but symbols.
 		if (i0 < work_end && h.kind >= 2 && i0 == next_part) {
 			read_part(i0);
 			if (r.err) {
@@ -322,54 +325,69 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				seg_end = 0;
 			}
 		}
-		// ---- the plain block ----
+		// ---- plain blocks ----
 		// Most blocks are sixteen Rice symbols of one parameter for every lane that is still reading, each symbol inside
 		// the next 32 bits, all words in the ring.  Such a block runs without a single branch or comparison against the
 		// sample index: count of leading zeros, saturating add, the window stepped on by at most one word (the word after
 		// next and the one after that are held in registers, the second requested a symbol before it can be needed), and
 		// the largest symbol length seen is looked at once, afterwards.  Should a symbol have been longer than 32 bits (or
-		// the stream have run out into the zeros behind it), nothing is kept and the block is done again the careful way.
-		// Lanes with nothing to read (constant subframes, finished or broken frames, lanes without a frame) compute
-		// garbage alongside and are put right at the end.
+		// the stream have run out into the zeros behind it), nothing is kept and the samples are done again the careful
+		// way.  Lanes with nothing to read (constant subframes, finished or broken frames, lanes without a frame) compute
+		// garbage alongside and are put right at the end.  What surrounds a block - the input pump, these tests, handing
+		// the samples on - costs as much as ten of its samples, so where every lane has a whole run (LDS::run) of plain symbols ahead
+		// the blocks of the run go through back to back.
 		const bool idle = i0 >= work_end;
-		const bool plain = i0 + DEC_BLOCK <= seg_end && i0 + DEC_BLOCK <= work_end && r.wrel + 2 * DEC_BLOCK < r.limit;
+		uint32_t nplain = 0;
+		const uint32_t DEC_RUN = run_len;   // at most LDS::run
+		{
+			const uint32_t lim = seg_end < work_end ? seg_end : work_end;
+			const bool run_ok = i0 + DEC_RUN <= lim && r.wrel + DEC_RUN + 2 < r.limit;
+			const bool blk_ok = i0 + DEC_BLOCK <= lim && r.wrel + 2 * DEC_BLOCK < r.limit;
+			if (i0 + DEC_RUN <= bs_w && __all(idle || run_ok))
+				nplain = DEC_RUN;
+			else if (__all(idle || blk_ok))
+				nplain = DEC_BLOCK;
+		}
 		bool block_done = false;
-		if (__all(idle || plain)) {
+		if (nplain) {
 			uint32_t cur = r.cur, nxt = r.nxt, rem = r.rem, wrel = r.wrel;
-			uint32_t n2 = r.ring[wrel & (RING_WORDS - 1)], n3 = r.ring[(wrel + 1) & (RING_WORDS - 1)];
+			uint32_t n2 = r.ring[wrel & r.rmask], n3 = r.ring[(wrel + 1) & r.rmask];
 			uint32_t tmax = 0;
-			// the history as it is now, in case the block has to be done again: kept in the warm-up samples' place in
-			// LDS, which nobody reads any more once a partition parameter has been read (a second copy in registers
-			// costs up to 32 of them, and the single-pass instances their second wave per SIMD)
+			// the history as it is now, in case the samples have to be done again: kept in the warm-up samples' place in
+			// LDS, which nobody reads any more once a partition parameter has been read
 			if (M > 0 && tid < LW) {
 #pragma unroll
 				for (int j = 0; j < M; j++)
 					L.w[j][lane] = hist[j];
 			}
+#pragma nounroll
+			for (uint32_t b0 = 0; b0 < nplain; b0 += DEC_BLOCK) {
+				int32_t *const bslot = slot + b0 * sstride;
 #pragma unroll
-			for (uint32_t s = 0; s < DEC_BLOCK; s++) {
-				const uint32_t win = __builtin_amdgcn_alignbit(cur, nxt, rem);
-				uint32_t z, total;
-				asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
-				asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
-				tmax = total > tmax ? total : tmax;
-				const int32_t left = (int32_t)rem - (int32_t)total;
-				const bool cross = left < 0;
-				cur = cross ? nxt : cur;
-				nxt = cross ? n2 : nxt;
-				n2 = cross ? n3 : n2;
-				wrel += cross ? 1u : 0u;
-				rem = (uint32_t)left & 31u;
-				n3 = r.ring[(wrel + 1) & (RING_WORDS - 1)];
-				if (!SKIP) {
-					const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
-					const uint32_t uf = (z << k) | lsbs;
-					const int32_t res = (int32_t)(uf >> 1) ^ __builtin_amdgcn_sbfe((int32_t)uf, 0, 1);
-					slot[s * LW] = (int32_t)((uint32_t)restore(res) << h.wasted);
+				for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+					const uint32_t win = __builtin_amdgcn_alignbit(cur, nxt, rem);
+					uint32_t z, total;
+					asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
+					asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
+					tmax = total > tmax ? total : tmax;
+					const int32_t left = (int32_t)rem - (int32_t)total;
+					const bool cross = left < 0;
+					cur = cross ? nxt : cur;
+					nxt = cross ? n2 : nxt;
+					n2 = cross ? n3 : n2;
+					wrel += cross ? 1u : 0u;
+					rem = (uint32_t)left & 31u;
+					n3 = r.ring[(wrel + 1) & r.rmask];
+					if (!SKIP) {
+						const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
+						const uint32_t uf = (z << k) | lsbs;
+						const int32_t res = (int32_t)(uf >> 1) ^ __builtin_amdgcn_sbfe((int32_t)uf, 0, 1);
+						bslot[s * sstride] = (int32_t)((uint32_t)restore(res) << h.wasted);
+					}
 				}
 			}
-			if (!__any(plain && tmax > 32)) {
-				if (plain) {
+			if (!__any(!idle && tmax > 32)) {
+				if (!idle) {
 					r.cur = cur;
 					r.nxt = nxt;
 					r.rem = rem;
@@ -377,19 +395,29 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				}
 				if (!SKIP && __any(idle && tid < LW)) {
 					if (idle) {
-#pragma unroll
-						for (uint32_t s = 0; s < DEC_BLOCK; s++)
-							slot[s * LW] = (int32_t)((uint32_t)h.constant << h.wasted);
+						for (uint32_t s = 0; s < nplain; s++)
+							slot[s * sstride] = (int32_t)((uint32_t)h.constant << h.wasted);
 					}
 				}
 				block_done = true;
-			} else if (M > 0 && tid < LW) {
+			} else {
+				nplain = 0;
+				if (M > 0 && tid < LW) {
 #pragma unroll
-				for (int j = 0; j < M; j++)
-					hist[j] = L.w[j][lane];
+					for (int j = 0; j < M; j++)
+						hist[j] = L.w[j][lane];
+				}
 			}
 		}
+		uint32_t nout = nplain;
 		if (!block_done) {
+		nout = DEC_BLOCK;
+		// (a stream that ends early feeds zeros, which no plain block gets through: the end is looked for here)
+		if (br_pos(r) > r.bend) {
+			r.err = true;
+			work_end = 0;
+			seg_end = 0;
+		}
 		// the fast path takes at most one word per sample
 		fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 		// SKIP: a sample is half a dozen instructions, fewer cycles than an LDS read takes, so the ring is read two
@@ -397,8 +425,8 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		// needed (garbage while the ring has not got that far, which is when fast_end is 0 and nothing uses them)
 		uint32_t n2 = 0, n3 = 0;
 		if (SKIP) {
-			n2 = r.ring[r.wrel & (RING_WORDS - 1)];
-			n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+			n2 = r.ring[r.wrel & r.rmask];
+			n3 = r.ring[(r.wrel + 1) & r.rmask];
 		}
 		// unrolled in full: the history needs no moves at all, and the compiler schedules across samples
 		// (unrolled by four: 1.70 ms for the benchmark's frames, in full: 1.63)
@@ -406,7 +434,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		for (uint32_t s = 0; s < DEC_BLOCK; s++) {
 			const uint32_t i = i0 + s;
 			// the word a step into the next word at the end of this sample would bring in
-			const uint32_t ring_word = SKIP ? n2 : r.ring[r.wrel & (RING_WORDS - 1)];
+			const uint32_t ring_word = SKIP ? n2 : r.ring[r.wrel & r.rmask];
 			// FLAC__bitreader_read_rice_signed_block (bitreader.c:775), symbol inside the next 32 bits: count of
 			// leading zeros (all ones for "none of the 32 is set": the saturating add then fails the length test),
 			// stop bit, k low bits
@@ -429,7 +457,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				r.rem = (uint32_t)left & 31u;
 				if (SKIP) {
 					n2 = cross ? n3 : n2;
-					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+					n3 = r.ring[(r.wrel + 1) & r.rmask];
 				}
 			}
 			if (!fast && i < work_end) {
@@ -455,21 +483,22 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				}
 				fast_end = r.wrel + 2 * DEC_BLOCK < r.limit ? seg_end : 0;
 				if (SKIP) {
-					n2 = r.ring[r.wrel & (RING_WORDS - 1)];
-					n3 = r.ring[(r.wrel + 1) & (RING_WORDS - 1)];
+					n2 = r.ring[r.wrel & r.rmask];
+					n3 = r.ring[(r.wrel + 1) & r.rmask];
 				}
 			}
 			const int32_t v = restore(res);
 			if (!SKIP)
-				slot[s * LW] = (int32_t)((uint32_t)v << h.wasted);
+				slot[s * sstride] = (int32_t)((uint32_t)v << h.wasted);
 		}
 		}
 		if (!SKIP) {
-			// the block goes out with all 64 threads along memory order
-			const uint32_t nblk = (i0 + DEC_BLOCK < bs_w ? DEC_BLOCK : bs_w - i0) * LW;
+			// the samples go out with all 64 threads along memory order
+			const uint32_t nblk = (i0 + nout < bs_w ? nout : bs_w - i0) * LW;
 			for (uint32_t e = tid; e < nblk; e += DEC_LANES)
 				plane[(size_t)i0 * LW + e] = L.out[e];
 		}
+		i0 += nout;
 	}
 }
 
@@ -496,12 +525,15 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 #define DEC_SUB 2
 #define DEC_NO_START 0xffffffffffffffffull
 
-template <int MODE, int MAXLW>
+// DEEP: four chunks per ring instead of two (and room for runs of four blocks): half as much LDS again per wave, so only
+// for launches whose waves all find room on the chip even so (the launcher decides)
+template <int MODE, int MAXLW, bool DEEP>
 __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
                                                           FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start,
                                                           uint32_t chain)
 {
-	__shared__ DecLds<MAXLW> L;
+	__shared__ DecLds<MAXLW, (DEEP ? RING_WORDS_BIG : RING_WORDS_MIN)> L;
+	const uint32_t run_len = umin_u32(P.run, (uint32_t)(DEEP ? DEC_RUN_BIG : DEC_RUN_MIN));
 	const uint32_t tid = threadIdx.x;
 	const uint32_t ncand = ncand_ptr[0];
 	const bool chained = MODE == DEC_SUB && chain != DEC_NO_CHAIN;
@@ -546,6 +578,7 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 		r.bend = endless ? 0xf0000000u : (uint32_t)rel;
 	}
 	r.ring = L.ring[lane];
+	r.rmask = (DEEP ? RING_WORDS_BIG : RING_WORDS_MIN) - 1;
 	// the first two chunks of every frame, all requested before the first is waited for
 	{
 		uint32_t first[2 * MAXLW];
@@ -674,12 +707,12 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 		const bool run = live && !r.err;
 #define DECODE(M) \
 	do { \
-		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
-		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
-		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords); \
+		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
+		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
+		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
 	} while (0)
 		if (MODE == DEC_SKIP) {
-			decode_samples<0, false, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords);
+			decode_samples<0, false, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len);
 			continue;
 		}
 		if (need == 0) DECODE(0);
@@ -748,11 +781,11 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 
 
 // what every dec_frames_*.hip defines: the launch of its instance
-#define DEC_FRAMES_LAUNCHER(name, MODE, MAXLW) \
+#define DEC_FRAMES_LAUNCHER(name, MODE, MAXLW, DEEP) \
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
 	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st) \
 	{ \
-		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
+		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW, DEEP>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
 	}
 
 #endif

@@ -1,4 +1,4 @@
 // One instance of the frame decoder kernel (see dec_frames.h for why each has a file of its own).
 #include "dec_frames.h"
 
-DEC_FRAMES_LAUNCHER(fa_dec_frames_sub16, DEC_SUB, 16)
+DEC_FRAMES_LAUNCHER(fa_dec_frames_sub16, DEC_SUB, 16, false)

@@ -12,7 +12,7 @@ struct FaDecParams {
 	uint32_t number_scale;   // samples per frame number in fixed-blocksize headers
 	uint32_t lw;             // frames per wave in k_dec_frames and per group in the scratch planes (power of two <= 64)
 	uint32_t skip_lw;        // frames per wave in the walk of the split form (which does not touch the planes)
-	uint32_t pad;
+	uint32_t run;            // samples between the frame decoder's service points where nothing but plain symbols lies ahead (16, 32, 64)
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
 };

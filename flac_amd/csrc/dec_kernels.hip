@@ -18,6 +18,8 @@
 // bad CRC (stream_decoder.c:2105-2113).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dec_kernels.h"
 #include "dec_frames.h"
 
@@ -689,26 +691,45 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
 	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st)
 DEC_FRAMES_DECL(fa_dec_frames_skip16);
+DEC_FRAMES_DECL(fa_dec_frames_skip16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub16);
+DEC_FRAMES_DECL(fa_dec_frames_sub16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub32);
 
 // split: walk, then every (frame, channel) at once; else one launch per channel, in order (see dec_frames.h)
-void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
+void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
                           int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st)
 {
+	FaDecParams P = Pin;
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
 	const uint32_t *words = (const uint32_t *)flac;
+	// The deep-ring instances take 24 KB of LDS per wave, six waves per CU: used while every wave of the launch still
+	// finds room at once on the 256 CUs; beyond that the shallow ones, whose pump (four refills of 64 words per service
+	// point) feeds runs of two blocks of streams of up to 16 bits and single blocks of wider ones.
+	uint32_t deep_waves = 256 * 6;
+	uint32_t shallow_run = P.bps <= 16 ? 32u : 16u;
+	// experiment switches: FLAC_AMD_DEC_RUN = run length of the shallow instances, FLAC_AMD_DEC_DEEP = most waves for the deep ones
+	if (const char *env = getenv("FLAC_AMD_DEC_RUN"))
+		shallow_run = (uint32_t)atoi(env);
+	if (const char *env = getenv("FLAC_AMD_DEC_DEEP"))
+		deep_waves = (uint32_t)atoi(env);
 	if (split && P.channels >= 2 && P.lw <= 16 && P.skip_lw <= 16) {
-		fa_dec_frames_skip16(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, (P.max_frames + P.skip_lw - 1) / P.skip_lw, 0xffffffffu, st);
-		fa_dec_frames_sub16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups * P.channels, 0xffffffffu, st);
+		const uint32_t walk_waves = (P.max_frames + P.skip_lw - 1) / P.skip_lw, sub_waves = groups * P.channels;
+		P.run = walk_waves <= deep_waves ? 64u : shallow_run;
+		(walk_waves <= deep_waves ? fa_dec_frames_skip16d : fa_dec_frames_skip16)(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, walk_waves, 0xffffffffu, st);
+		P.run = sub_waves <= deep_waves ? 64u : shallow_run;
+		(sub_waves <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, st);
 		return;
 	}
 	// the largest batches put 32 frames into a wave (twice the LDS, half the waves)
 	for (uint32_t c = 0; c < P.channels; c++) {
-		if (P.lw <= 16)
-			fa_dec_frames_sub16(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
-		else
+		if (P.lw <= 16) {
+			P.run = groups <= deep_waves ? 64u : shallow_run;
+			(groups <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+		} else {
+			P.run = 16;   // (32 lanes of a wave read 32 samples' worth of words faster than four refills per service point bring them)
 			fa_dec_frames_sub32(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+		}
 	}
 }
 
