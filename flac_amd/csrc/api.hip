@@ -87,6 +87,7 @@ struct flacamd_encoder {
 	uint32_t *frame_bytes;
 	uint64_t *offsets;
 	uint32_t *errflag;    // [0] device error bits, [1] loose mid/side state out
+	int32_t *planes;      // streams of three or more channels: the batch's samples as 32-bit planes per frame (k_planes)
 	// staging for the host-buffer entry point
 	int32_t *stage_pcm;
 	int16_t *stage_host16;  // pinned: samples narrowed to 16 bits before they cross PCIe
@@ -173,6 +174,7 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 	(void)hipFree(e->plans);
 	(void)hipFree(e->assign);
 	(void)hipFree(e->slots);
+	(void)hipFree(e->planes);
 	(void)hipFree(e->frame_bytes);
 	(void)hipFree(e->offsets);
 	(void)hipFree(e->errflag);
@@ -231,6 +233,15 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	ALLOC(e->plans, sizeof(FaPlan) * F * S);
 	ALLOC(e->assign, sizeof(uint32_t) * F);
 	ALLOC(e->slots, (size_t)P.slot_bytes * F + 64);
+	// Three or more interleaved channels: a workgroup that takes ONE channel out of them uses 4 of every 4 x channels
+	// bytes it fetches, and every channel's workgroup fetches every line.  Such streams are laid out again first, frame
+	// by frame, as planes (one pass over the samples; FLAC_AMD_PLANES=0 switches it off, =1 on for two channels too).
+	{
+		const char *env = getenv("FLAC_AMD_PLANES");
+		const bool on = env ? (atoi(env) != 0 && p.channels >= 2) : p.channels >= 3;
+		if (on)
+			ALLOC(e->planes, sizeof(int32_t) * F * p.channels * p.blocksize);
+	}
 	ALLOC(e->frame_bytes, sizeof(uint32_t) * F);
 	ALLOC(e->offsets, sizeof(uint64_t) * (F + 1));
 	ALLOC(e->errflag, 16);
@@ -303,6 +314,7 @@ extern "C" int flacamd_encoder_stage_ms(flacamd_encoder *e, float ms[FLACAMD_ENC
 
 // The device buffers one batch works in, whoever owns them.
 struct EncWork {
+	int32_t *planes;      // null: the kernels read the caller's samples as they lie
 	const float *windows;
 	FaSubStat *stats;
 	float *autoc;
@@ -338,15 +350,17 @@ static int check_batch(const FaEncParams &P, const void *pcm_dev, const void *ou
 	B.sample_bytes = sample_bytes;
 	B.loose_carry = loose_state ? *loose_state : 0;
 	B.pairs = (sample_bytes == 2 && P.channels == 2 && ((uintptr_t)pcm_dev & 3) == 0) ? 1u : 0u;
-	B.pad = 0;
+	B.planar = 0;
 	return FLACAMD_OK;
 }
 
 // The kernel sequence of one batch.  ev: FLACAMD_ENC_STAGES + 1 events to record between the
 // stages, or null.
-static int run_batch(const FaEncParams &P, const FaBatch &B, const EncWork &W, const void *pcm_dev, void *out_dev, size_t out_capacity,
+static int run_batch(const FaEncParams &P, const FaBatch &Bin, const EncWork &W, const void *pcm_in, void *out_dev, size_t out_capacity,
                      uint32_t *fb, uint64_t *fo, hipStream_t st, hipEvent_t *ev)
 {
+	FaBatch B = Bin;
+	const void *pcm_dev = pcm_in;
 	int evi = 0;
 #define STAGE_MARK() \
 	do { \
@@ -355,6 +369,12 @@ static int run_batch(const FaEncParams &P, const FaBatch &B, const EncWork &W, c
 	} while (0)
 	const char *stamps_env = getenv("FLAC_AMD_STAMPS");
 	STAGE_MARK();
+	if (W.planes && !B.pairs) {
+		fa_launch_planes(P, B, pcm_in, W.planes, st);
+		B.planar = P.blocksize;
+		B.sample_bytes = 4;
+		pcm_dev = W.planes;
+	}
 	fa_launch_analyze(P, B, pcm_dev, W.stats, st);
 	STAGE_MARK();
 	if (P.max_lpc_order > 0)
@@ -402,6 +422,7 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	HIP_TRY(hipSetDevice(e->device));
 	hipStream_t st = (hipStream_t)stream;
 	EncWork W;
+	W.planes = e->planes;
 	W.windows = e->windows;
 	W.stats = e->stats;
 	W.autoc = e->autoc;
@@ -634,6 +655,7 @@ extern "C" int flacamd_encode_frames_static(const flacamd_encode_params *pin, in
 		}
 	}
 	EncWork W;
+	W.planes = nullptr;   // (planes of a whole batch would not fit the static buffer)
 	W.windows = (const float *)(base + L.windows);
 	W.stats = (FaSubStat *)(base + L.stats);
 	W.autoc = (float *)(base + L.autoc);

@@ -20,6 +20,31 @@
 #include "enc_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
+// k_planes: the part of FLAC__stream_encoder_process_interleaved that takes the interleaved samples apart
+// (stream_encoder.c:2071-2097) for streams of three or more channels: 256 wide samples of a frame per
+// workgroup, read along memory, turned in LDS, written as one run per channel into the frame's block
+// [channel][blocksize] of 32-bit words.  Positions behind a short last block are never read by anyone.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_planes(FaEncParams P, FaBatch B, const void *pcm, int32_t *planes, uint32_t tiles)
+{
+	__shared__ int32_t t[FLACAMD_MAX_CHANNELS * 257];
+	const uint32_t f = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 256, tid = threadIdx.x;
+	const uint32_t bsf = frame_len(B, P.blocksize, f), ch = P.channels;
+	if (t0 >= bsf)
+		return;
+	const uint32_t n = umin32(256u, bsf - t0);
+	const uint64_t first = ((uint64_t)f * P.blocksize + t0) * ch;
+	for (uint32_t e = tid; e < n * ch; e += 256) {
+		const uint32_t i = e / ch, c = e - i * ch;
+		t[c * 257 + i] = read_pcm(pcm, B.sample_bytes, first + e);
+	}
+	__syncthreads();
+	if (tid < n)
+		for (uint32_t c = 0; c < ch; c++)
+			planes[((size_t)f * ch + c) * P.blocksize + t0 + tid] = t[c * 257 + tid];
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_analyze: get_wasted_bits_ (stream_encoder.c:4108) + FLAC__fixed_compute_best_predictor[_wide]
 // (fixed.c:224,282) + the all-samples-equal test of process_subframe_ (:3210-3227)
 // ---------------------------------------------------------------------------------------------
@@ -42,7 +67,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 	// staged (unshifted) for pass 2.  Loads are issued a tile at a time, back to back.
 	constexpr uint32_t HP = ST_HP(4);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
-	const SigAccess acc = sig_access(P.channels, B.sample_bytes, B.pairs, s);
+	const SigAccess acc = sig_access(P.channels, B.sample_bytes, fa_layout(B), s);
 	int32_t first;
 	uint32_t orv = 0, ne = 0;
 	{
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 	}
 	for (uint32_t t0 = FA_TILE; t0 < bsf; t0 += FA_TILE) {
 		int32_t v[NIT];
-		stage_load<4>(v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, t0);
+		stage_load<4>(v, pcm, P.channels, B.sample_bytes, fa_layout(B), frame_start, bsf, s, t0);
 #pragma unroll
 		for (uint32_t i = 0; i < NIT; i++) {
 			const uint32_t j = tid + i * FA_THREADS;
@@ -97,7 +122,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
 			if (tile > 0) {
 				__syncthreads();
-				stage_tile<4>(stage, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, s, 0, tile * FA_TILE);
+				stage_tile<4>(stage, pcm, P.channels, B.sample_bytes, fa_layout(B), frame_start, bsf, s, 0, tile * FA_TILE);
 				__syncthreads();
 			}
 			const uint32_t base = tile * FA_TILE + tid * FA_CHUNK;
@@ -546,7 +571,10 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 				const uint32_t bsf = frame_len(B, P.blocksize, f);
 				const uint32_t idx = c0 + k;
 				if (idx < bsf) {
-					const int32_t smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, (uint64_t)f * P.blocksize + idx, s) >> stats[sub].wasted;
+					// (planes: the frame's block and the position inside it are at hand, no division needed to find them)
+					const int32_t raw = B.planar ? frame_plane_signal((const int32_t *)pcm + (size_t)f * P.blocksize * P.channels + idx, P.channels, P.blocksize, s)
+					                             : fetch_signal(pcm, P.channels, B.sample_bytes, fa_layout(B), (uint64_t)f * P.blocksize + idx, s);
+					const int32_t smp = raw >> stats[sub].wasted;
 					v = __fmul_rn((float)smp, windows[(size_t)a * P.blocksize + idx]);
 				}
 			}
@@ -917,6 +945,12 @@ __global__ __launch_bounds__(FA_THREADS) void k_compact(const uint32_t *slots, u
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+void fa_launch_planes(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, hipStream_t st)
+{
+	const uint32_t tiles = (P.blocksize + 255) / 256;
+	hipLaunchKernelGGL(k_planes, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, tiles);
+}
+
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st)
 {
 	if (B.pairs && P.nsignals == 4 && !P.wide_fixed)

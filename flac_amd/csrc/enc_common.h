@@ -35,10 +35,28 @@ __device__ __forceinline__ int32_t read_pcm(const void *pcm, uint32_t sample_byt
 }
 
 // Signal s of a wide sample: an input channel, or mid = (L+R)>>1 / side = L-R
-// (stream_encoder.c:1991-1992, arithmetic shift, not a division).  `pairs`: the buffer is 16-bit
-// stereo on a 4-byte boundary, so one 32-bit load brings both channels.
+// (stream_encoder.c:1991-1992, arithmetic shift, not a division).  `layout` (fa_layout): 0 the caller's interleaved
+// samples of sample_bytes each; 1 "pairs", the buffer is 16-bit stereo on a 4-byte boundary, so one 32-bit load brings
+// both channels; a blocksize: the samples have been laid out again frame by frame as 32-bit planes,
+// [frame][channel][blocksize] (k_planes), so that a workgroup that reads one channel reads whole cache lines.
+__device__ __forceinline__ uint32_t fa_layout(const FaBatch &B) { return B.pairs ? 1u : B.planar; }
+
+// signal s at one position of a frame's block of planes: fr points at channel 0's sample
+__device__ __forceinline__ int32_t frame_plane_signal(const int32_t *fr, uint32_t channels, uint32_t bs, uint32_t s)
+{
+	if (s < channels)
+		return fr[(size_t)s * bs];
+	const int32_t l = fr[0], r = fr[bs];
+	return s == channels ? ((l + r) >> 1) : (l - r);
+}
+
 __device__ __forceinline__ int32_t fetch_signal(const void *pcm, uint32_t channels, uint32_t sample_bytes, uint32_t pairs, uint64_t wide, uint32_t s)
 {
+	if (pairs > 1) {
+		const uint32_t bs = pairs;
+		const uint64_t f = wide / bs;
+		return frame_plane_signal((const int32_t *)pcm + f * bs * channels + (wide - f * bs), channels, bs, s);
+	}
 	if (pairs) {
 		const uint32_t w = ((const uint32_t *)pcm)[wide];
 		const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
@@ -88,16 +106,21 @@ struct SigAccess {
 	uint32_t kind;    // 0 a channel, 1 mid, 2 side
 	uint32_t ca, cb;  // the channel(s) read
 	uint32_t channels;
+	uint32_t mul, offa, offb;   // sample `rel` of the frame, channel ca / cb: element rel * mul + offa / offb behind the frame's first
 };
 
 __device__ __forceinline__ SigAccess sig_access(uint32_t channels, uint32_t sample_bytes, uint32_t pairs, uint32_t s)
 {
 	SigAccess a;
-	a.fmt = pairs ? 0 : sample_bytes;
+	a.fmt = pairs == 1 ? 0 : (pairs ? 4 : sample_bytes);
 	a.kind = s < channels ? 0 : (s == channels ? 1 : 2);
 	a.ca = a.kind ? 0 : s;
 	a.cb = a.kind ? 1 : s;
 	a.channels = channels;
+	// interleaved: sample-major; planes (pairs = the blocksize): channel-major inside the frame's block
+	a.mul = pairs > 1 ? 1u : channels;
+	a.offa = pairs > 1 ? a.ca * pairs : a.ca;
+	a.offb = pairs > 1 ? a.cb * pairs : a.cb;
 	return a;
 }
 
@@ -125,8 +148,8 @@ __device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *p
 		int32_t x[N], y[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			x[i] = base[rel[i] * a.channels + a.ca];
-			y[i] = base[rel[i] * a.channels + a.cb];
+			x[i] = base[rel[i] * a.mul + a.offa];
+			y[i] = base[rel[i] * a.mul + a.offb];
 		}
 #pragma unroll
 		for (int i = 0; i < N; i++)
@@ -136,8 +159,8 @@ __device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *p
 		int32_t x[N], y[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			x[i] = base[rel[i] * a.channels + a.ca];
-			y[i] = base[rel[i] * a.channels + a.cb];
+			x[i] = base[rel[i] * a.mul + a.offa];
+			y[i] = base[rel[i] * a.mul + a.offb];
 		}
 #pragma unroll
 		for (int i = 0; i < N; i++)
@@ -148,8 +171,8 @@ __device__ __forceinline__ void load_signal_block(int32_t (&v)[N], const void *p
 		int32_t x2[N], y2[N];
 #pragma unroll
 		for (int i = 0; i < N; i++) {
-			const uint8_t *px = base + (rel[i] * a.channels + a.ca) * 3;
-			const uint8_t *py = base + (rel[i] * a.channels + a.cb) * 3;
+			const uint8_t *px = base + (rel[i] * a.mul + a.offa) * 3;
+			const uint8_t *py = base + (rel[i] * a.mul + a.offb) * 3;
 			x0[i] = px[0]; x1[i] = px[1]; x2[i] = (int8_t)px[2];
 			y0[i] = py[0]; y1[i] = py[1]; y2[i] = (int8_t)py[2];
 		}

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 					const uint32_t j = HP + tid;
 					smp = quad_signal((uint32_t)T.v[j + (j >> 4)], sig) >> wasted;
 				} else
-					smp = fetch_signal(pcm, P.channels, B.sample_bytes, B.pairs, frame_start + tid, sig) >> wasted;
+					smp = fetch_signal(pcm, P.channels, B.sample_bytes, fa_layout(B), frame_start + tid, sig) >> wasted;
 				emit_bits(S, pos + tid * sbps, sbps, (uint32_t)smp);
 			}
 			pos += order * sbps;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 		uint32_t tile_start_bit = pos;
 		for (uint32_t tile = 0; tile * FA_TILE < bsf; tile++) {
 			if (!QUAD) {
-				stage_tile<HIST>(T.v, pcm, P.channels, B.sample_bytes, B.pairs, frame_start, bsf, sig, wasted, tile * FA_TILE);
+				stage_tile<HIST>(T.v, pcm, P.channels, B.sample_bytes, fa_layout(B), frame_start, bsf, sig, wasted, tile * FA_TILE);
 				__syncthreads();
 			} else if (bsf > FA_TILE) {
 				// more than one tile: each is staged when its turn comes, raw like the first

@@ -238,7 +238,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 	for (uint32_t k = 0; k < SR_PRE_COEFS / FA_THREADS; k++)
 		pre_q[k] = (tid + k * FA_THREADS < npre_coefs) ? my_coefs[tid + k * FA_THREADS] : 0;
 	int32_t tile_v[NIT];
-	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, 0);
+	stage_load<HIST>(tile_v, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : B.planar, frame_start, bsf, s, 0);
 	const FaSubStat st = stats[task];
 	const uint32_t sbps = st.bps, wasted = st.wasted;
 	const uint32_t hdr = 8 + wasted;
@@ -466,7 +466,7 @@ void k_search(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
 		for (uint32_t tile = 0; tile < ntiles; tile++) {
 			if (!(tile == 0 && staged)) {
 				__syncthreads();
-				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : 0u, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
+				stage_tile<HIST>(stage, pcm, P.channels, B.sample_bytes, PAIRS ? 1u : B.planar, frame_start, bsf, s, wasted, tile * FA_TILE, opaque_tid());
 			}
 			__syncthreads();
 			staged = false;

@@ -412,7 +412,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 		// lanes along consecutive samples, stored as rows of 64, and sixteen lanes pick up a row each
 		// plus the tail of the row before it ----
 		int32_t d[SW_W];
-		SigAccess acc = sig_access(P.channels, B.sample_bytes, B.pairs, s);
+		SigAccess acc = sig_access(P.channels, B.sample_bytes, fa_layout(B), s);
 		if (PAIRS)
 			acc.fmt = 0;
 		sw_load_run(d, stage, pcm, acc, frame_start, bsf, partial, wasted, ln);
@@ -682,7 +682,7 @@ void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const
 				SwCand k;
 				if (!candidate(c, k) || (RES == SW_SPLIT ? sw_split_fold(k.sumq, k.shift, sbps, k.mode == 2u).exact : fa_fold_exact(k.sumq, k.shift, fold_bps)))
 					continue;
-				const uint32_t t = sw_lane_sum_exact(pcm, P.channels, B.sample_bytes, B.pairs, frame_start, s, wasted, ln, k.q, k.order, (int)k.shift, k.mode != 2u, bsf);
+				const uint32_t t = sw_lane_sum_exact(pcm, P.channels, B.sample_bytes, fa_layout(B), frame_start, s, wasted, ln, k.q, k.order, (int)k.shift, k.mode != 2u, bsf);
 				consider(c, k, t, true);
 			}
 		}

@@ -40,7 +40,7 @@ struct FaBatch {
 	uint32_t sample_bytes;        // 2, 3 or 4
 	uint32_t loose_carry;         // assignment of the leader frame preceding this batch
 	uint32_t pairs;               // 16-bit stereo on a 4-byte boundary: one 32-bit load per wide sample
-	uint32_t pad;
+	uint32_t planar;              // 0, or the blocksize: the kernels read 32-bit planes [frame][channel][blocksize] made by k_planes
 };
 
 // Per (frame, signal) statistics from the analysis pass.
