@@ -23,7 +23,9 @@ struct flacamd_decoder {
 	uint32_t max_streams;
 	FaStream *streams;
 	uint32_t *block_counts;
-	uint64_t *block_offsets;
+	uint64_t *crc_ahead;            // per header: the CRC pass that runs beside the frame decoder leaves its guess and verdict here
+	hipStream_t side;               // that pass and the clearing of the output run here, between ev_fork and ev_join
+	hipEvent_t ev_fork, ev_join;
 	FaFrameCand *cands;
 	uint32_t *ncand;                // [0] count, [1] overflow flag
 	int32_t *tmp;
@@ -46,7 +48,13 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipSetDevice(d->device);
 	(void)hipFree(d->streams);
 	(void)hipFree(d->block_counts);
-	(void)hipFree(d->block_offsets);
+	(void)hipFree(d->crc_ahead);
+	if (d->side)
+		(void)hipStreamDestroy(d->side);
+	if (d->ev_fork)
+		(void)hipEventDestroy(d->ev_fork);
+	if (d->ev_join)
+		(void)hipEventDestroy(d->ev_join);
 	(void)hipFree(d->cands);
 	(void)hipFree(d->ncand);
 	(void)hipFree(d->tmp);
@@ -105,7 +113,19 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	ALLOC(d->streams, sizeof(FaStream) * d->max_streams);
 	// per 4 KiB of input: a count of frame headers, and behind the counts four 64-bit lane masks
 	ALLOC(d->block_counts, sizeof(uint32_t) * ((size_t)nb + 2) + sizeof(uint64_t) * 4 * (size_t)nb);
-	ALLOC(d->block_offsets, sizeof(uint64_t) * (nb + 1));
+	{
+		// FLAC_AMD_DEC_SIDE=0: everything on the caller's stream, one kernel after the other
+		const char *env = getenv("FLAC_AMD_DEC_SIDE");
+		if (!(env && !strcmp(env, "0"))) {
+			ALLOC(d->crc_ahead, sizeof(uint64_t) * max_frames);
+			if (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+			    hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming) != hipSuccess ||
+			    hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming) != hipSuccess) {
+				flacamd_decoder_destroy(d);
+				return fa_fail(FLACAMD_E_DEVICE, "creating the decoder's second stream failed");
+			}
+		}
+	}
 	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
 	ALLOC(d->ncand, 16);
 	ALLOC(d->tmp, sizeof(int32_t) * groups * 64 * channels * max_blocksize);
@@ -233,8 +253,6 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	}
 	static_assert(sizeof(FaStream) == sizeof(flacamd_stream_desc), "stream descriptor layout");
 	HIP_TRY(hipMemcpyAsync(d->streams, streams_host, sizeof(FaStream) * nstreams, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemsetAsync(d->ncand, 0, 16, st));
-	HIP_TRY(hipMemsetAsync(d->result, 0, 32, st));
 	FaDecParams P;
 	P.channels = d->channels;
 	P.bps = d->bps;
@@ -256,13 +274,28 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 			HIP_TRY(hipEventRecord(d->ev[evi++], st)); \
 	} while (0)
 	STAGE_MARK();
-	// frames that fail their checks leave zeros, like the reference's zeroed blocks
-	HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, (size_t)out_capacity_wide * d->channels * out_sample_bytes, st));
-	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->block_offsets, d->cands, d->ncand, st);
+	// Frames that fail their checks leave zeros, like the reference's zeroed blocks.  The frame decoder is a few long
+	// chains of dependent instructions and leaves most of the chip's bandwidth and issue slots idle: clearing the
+	// output and the CRC-16 of the frames (on the guess that each ends where the next header was found) run beside it
+	// on a second stream, forked and joined with events so that the caller's stream (or a graph captured from it)
+	// sees one ordered piece of work.
+	const size_t out_bytes = (size_t)out_capacity_wide * d->channels * out_sample_bytes;
+	if (!d->side)
+		HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, out_bytes, st));
+	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->cands, d->ncand, d->result, st);
+	if (d->side) {
+		HIP_TRY(hipEventRecord(d->ev_fork, st));
+		HIP_TRY(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+		HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, out_bytes, d->side));
+		fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, d->streams, d->crc_ahead, true, d->side);
+		HIP_TRY(hipEventRecord(d->ev_join, d->side));
+	}
 	STAGE_MARK();
 	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->sub_start, d->split != 0, st);
+	if (d->side)
+		HIP_TRY(hipStreamWaitEvent(st, d->ev_join, 0));
 	STAGE_MARK();
-	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, st);
+	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, d->streams, d->crc_ahead, false, st);
 	STAGE_MARK();
 	fa_dec_launch_output(P, d->streams, d->cands, d->ncand, d->tmp, pcm_out_dev, d->result, st);
 	STAGE_MARK();

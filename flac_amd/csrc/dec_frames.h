@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dec_kernels.h"
 
 #define DEC_LANES 64
@@ -148,6 +150,20 @@ struct DecLds {
 	int32_t out[run * MAXLW + 1];            // a run of decoded samples, [sample][lane]; the last word: for the lanes without a frame
 };
 
+// What the two waves of the pipelined form (DEC_PIPE) pass each other: the entropy wave leaves up to a run of values as
+// read from the stream (residuals, warm-up and verbatim samples, a constant) in res[0] and res[1] in turn, how many in
+// cnt[], and, once per subframe, what the restoring wave has to know about every lane's subframe.
+template <int MAXLW, int RUN>
+struct PipeLds {
+	int32_t res[2][RUN * MAXLW + 1];        // [sample][lane]; the last word: for the lanes without a frame
+	uint32_t cnt[2];
+	uint32_t order[MAXLW];                  // predictor order; 0 where there is no predictor
+	uint32_t wasted[MAXLW];
+	int32_t shift[MAXLW];
+	uint32_t flags[MAXLW];                  // bit 0: a predictor; bit 1: its sum needs 64 bits; bit 2: samples of up to 24 bits
+};
+struct NoPipe {};
+
 // The wave-level input pump.  Up to four refills are in flight (one word per thread each); they are
 // put into the rings at the next service point, a block of samples later.  (Four, because two cannot feed
 // sixteen lanes of 24-bit frames, 7.5 words per lane and block: 2.94 -> 1.96 ms for 14 063 such frames.)
@@ -225,10 +241,13 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_
 // at a time in LDS and written to plane[sample * LW + lane] by all threads together.
 // SKIP: the subframe is only walked through, to find where it ends: symbols are measured, not turned into
 // values, nothing is predicted or stored (M is 0).
-template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS>
+// PX = PipeLds: the values go to the restoring wave as they are (M is 0), a run at a time, instead of to the planes.
+template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS, typename PX = NoPipe>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
-                                               uint32_t bsf, bool live, uint64_t nwords, uint32_t run_len)
+                                               uint32_t bsf, bool live, uint64_t nwords, uint32_t run_len, PX *X = nullptr)
 {
+	constexpr bool PIPE = !std::is_same<PX, NoPipe>::value;
+	uint32_t hand = 0;   // PIPE: which of the two exchange buffers is being filled
 	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
 	// are switched on at the first residual; lanes without a predictor keep zeros
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
@@ -248,8 +267,13 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
 	// sample s of the run in hand goes to slot[s * sstride]; lanes that carry no frame all write to one spare word
-	int32_t *const slot = tid < LW ? &L.out[tid] : &L.out[LDS::run * LDS::maxlw];
+	int32_t *slot;
+	if constexpr (PIPE)
+		slot = tid < LW ? &X->res[0][tid] : &X->res[0][LDS::run * LDS::maxlw];
+	else
+		slot = tid < LW ? &L.out[tid] : &L.out[LDS::run * LDS::maxlw];
 	const uint32_t sstride = tid < LW ? LW : 0u;
+	const uint32_t up = PIPE ? 0u : h.wasted;   // (the restoring wave shifts the wasted bits back in)
 	// the partition parameter(s) due at sample i (stream_decoder.c:2741-2767); the predictor is switched on with the first
 	auto read_part = [&](uint32_t i) __attribute__((always_inline)) {
 		if (M > 0 && i == h.order) {
@@ -382,7 +406,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 						const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
 						const uint32_t uf = (z << k) | lsbs;
 						const int32_t res = (int32_t)(uf >> 1) ^ __builtin_amdgcn_sbfe((int32_t)uf, 0, 1);
-						bslot[s * sstride] = (int32_t)((uint32_t)restore(res) << h.wasted);
+						bslot[s * sstride] = (int32_t)((uint32_t)restore(res) << up);
 					}
 				}
 			}
@@ -396,7 +420,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				if (!SKIP && __any(idle && tid < LW)) {
 					if (idle) {
 						for (uint32_t s = 0; s < nplain; s++)
-							slot[s * sstride] = (int32_t)((uint32_t)h.constant << h.wasted);
+							slot[s * sstride] = (int32_t)((uint32_t)h.constant << up);
 					}
 				}
 				block_done = true;
@@ -489,16 +513,114 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			}
 			const int32_t v = restore(res);
 			if (!SKIP)
-				slot[s * sstride] = (int32_t)((uint32_t)v << h.wasted);
+				slot[s * sstride] = (int32_t)((uint32_t)v << up);
 		}
 		}
-		if (!SKIP) {
+		if constexpr (PIPE) {
+			// hand the run over: the restoring wave works on it while the next one is read into the other buffer
+			if (tid == 0)
+				X->cnt[hand] = i0 + nout < bs_w ? nout : bs_w - i0;
+			__syncthreads();
+			hand ^= 1u;
+			slot = tid < LW ? &X->res[hand][tid] : &X->res[hand][LDS::run * LDS::maxlw];
+		} else if (!SKIP) {
 			// the samples go out with all 64 threads along memory order
 			const uint32_t nblk = (i0 + nout < bs_w ? nout : bs_w - i0) * LW;
 			for (uint32_t e = tid; e < nblk; e += DEC_LANES)
 				plane[(size_t)i0 * LW + e] = L.out[e];
 		}
 		i0 += nout;
+	}
+}
+
+// The restoring wave of the pipelined form: FLAC__fixed_restore_signal (fixed.c:395) and FLAC__lpc_restore_signal[_wide]
+// (lpc.c:795,1061) over the values the entropy wave hands over, the wasted bits shifted back in
+// (stream_decoder.c:2511-2515), the samples collected a run at a time and written to the planes along memory order.
+// A lane's predictor is switched on at the sample that follows its warm-up; only the first blocks of a subframe
+// (up to the largest order in the wave) have to look for that sample.
+template <int M, bool WIDE, bool MUL24, typename LDS, typename PX>
+__device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t order, bool predictive,
+                                            int shift, bool lane_wide, uint32_t wasted, uint32_t need)
+{
+	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
+#pragma unroll
+	for (int j = 0; j < M; j++) {
+		q[j] = 0;
+		hist[j] = 0;
+	}
+	const uint32_t lane = tid < (uint32_t)LDS::maxlw ? tid : 0;
+	const uint32_t rstride = tid < LW ? LW : 0u, rbase = tid < LW ? tid : (uint32_t)(LDS::run * LDS::maxlw);
+	int32_t *const slot = &L.out[rbase];
+	auto step = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
+		int32_t v = res;
+		if (M > 0) {
+			int32_t pred;
+			if (WIDE) {
+				int64_t sum = 0;
+#pragma unroll
+				for (int j = 0; j < M; j++)
+					sum += (int64_t)q[j] * (int64_t)hist[j];
+				pred = lane_wide ? (int32_t)(sum >> shift) : ((int32_t)sum >> shift);
+			} else {
+				int32_t sum = 0;
+				if (MUL24) {
+					int32_t s0, s1 = 0;
+					asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s0) : "v"(q[0]), "v"(hist[0]));
+					if (M > 1)
+						asm("v_mul_i32_i24 %0, %1, %2" : "=v"(s1) : "v"(q[1]), "v"(hist[1]));
+#pragma unroll
+					for (int j = 2; j < M; j += 2) {
+						asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(q[j]), "v"(hist[j]), "v"(s0));
+						if (j + 1 < M)
+							asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(q[j + 1]), "v"(hist[j + 1]), "v"(s1));
+					}
+					sum = s0 + s1;
+				} else {
+#pragma unroll
+					for (int j = 0; j < M; j++)
+						sum += q[j] * hist[j];
+				}
+				pred = sum >> shift;
+			}
+			v = (int32_t)((uint32_t)res + (uint32_t)pred);
+#pragma unroll
+			for (int j = M - 1; j > 0; j--)
+				hist[j] = hist[j - 1];
+			hist[0] = v;
+		}
+		return v;
+	};
+	uint32_t hand = 0;
+	for (uint32_t i0 = 0; i0 < bs_w;) {
+		__syncthreads();
+		const uint32_t n = X.cnt[hand];
+		const int32_t *src = &X.res[hand][rbase];
+#pragma nounroll
+		for (uint32_t b0 = 0; b0 < n; b0 += DEC_BLOCK) {
+			const int32_t *bsrc = src + b0 * rstride;
+			int32_t *bslot = slot + b0 * rstride;
+			if (M > 0 && i0 + b0 <= need) {
+				// a block in which some lane's warm-up may end
+#pragma unroll
+				for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+					if (predictive && i0 + b0 + s == order) {
+#pragma unroll
+						for (int j = 0; j < M; j++)
+							q[j] = (uint32_t)j < order ? L.q[j][lane] : 0;
+					}
+					bslot[s * rstride] = (int32_t)((uint32_t)step(bsrc[s * rstride]) << wasted);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t s = 0; s < DEC_BLOCK; s++)
+					bslot[s * rstride] = (int32_t)((uint32_t)step(bsrc[s * rstride]) << wasted);
+			}
+		}
+		const uint32_t nblk = n * LW;
+		for (uint32_t e = tid; e < nblk; e += DEC_LANES)
+			plane[(size_t)i0 * LW + e] = L.out[e];
+		i0 += n;
+		hand ^= 1u;
 	}
 }
 
@@ -521,30 +643,78 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 // here; with two bodies per sample block the compiler needs more than 512 registers for it, and one launch per
 // channel is that loop without its cost.)
 #define DEC_NO_CHAIN 0xffffffffu
+// DEC_PIPE is DEC_SUB with two waves to a workgroup: the first reads the symbols, the second turns them into samples and
+// writes them out, a run behind.  Reading is the longer half, so the chain per subframe shrinks to that; the chip has
+// to have room for twice the waves, which is what the split form is used for anyway.
 #define DEC_SKIP 1
 #define DEC_SUB 2
+#define DEC_PIPE 3
 #define DEC_NO_START 0xffffffffffffffffull
 
 // DEEP: four chunks per ring instead of two (and room for runs of four blocks): half as much LDS again per wave, so only
 // for launches whose waves all find room on the chip even so (the launcher decides)
 template <int MODE, int MAXLW, bool DEEP>
-__global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
+__global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
                                                           FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start,
                                                           uint32_t chain)
 {
 	__shared__ DecLds<MAXLW, (DEEP ? RING_WORDS_BIG : RING_WORDS_MIN)> L;
+	constexpr bool SUBM = MODE == DEC_SUB || MODE == DEC_PIPE;   // one subframe per lane, from a known start
+	constexpr bool PIPE = MODE == DEC_PIPE;
+	using Xchg = PipeLds<MAXLW, (DEEP ? DEC_RUN_BIG : DEC_RUN_MIN)>;
+	__shared__ typename std::conditional<PIPE, Xchg, NoPipe>::type X;
 	const uint32_t run_len = umin_u32(P.run, (uint32_t)(DEEP ? DEC_RUN_BIG : DEC_RUN_MIN));
-	const uint32_t tid = threadIdx.x;
+	const uint32_t tid = threadIdx.x & (DEC_LANES - 1);
 	const uint32_t ncand = ncand_ptr[0];
-	const bool chained = MODE == DEC_SUB && chain != DEC_NO_CHAIN;
-	const uint32_t grp = (MODE == DEC_SUB && !chained) ? blockIdx.x / P.channels : blockIdx.x;
-	const uint32_t only_c = MODE == DEC_SUB ? (chained ? chain : blockIdx.x % P.channels) : 0;
+	const bool chained = SUBM && chain != DEC_NO_CHAIN;
+	const uint32_t grp = (SUBM && !chained) ? blockIdx.x / P.channels : blockIdx.x;
+	const uint32_t only_c = SUBM ? (chained ? chain : blockIdx.x % P.channels) : 0;
 	if (grp * LW >= ncand)
 		return;
 	const uint32_t j = grp * LW + tid;
 	const bool have_frame = tid < LW && j < ncand;
 	bool live = have_frame;
 	const uint32_t lane = tid < (uint32_t)MAXLW ? tid : 0;
+	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * LW;
+	if constexpr (PIPE) {
+		if (threadIdx.x >= DEC_LANES) {
+			// ---- the restoring wave ----
+			uint32_t bs_w = have_frame ? cands[j].blocksize : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const uint32_t t = __shfl_xor(bs_w, o, 64);
+				bs_w = t > bs_w ? t : bs_w;
+			}
+			int32_t *plane = frame_tmp + (size_t)only_c * P.max_blocksize * LW;
+			__syncthreads();   // the subframe headers are in
+			const uint32_t flags = tid < LW ? X.flags[lane] : 0;
+			const bool predictive = flags & 1u, lane_wide = flags & 2u;
+			const uint32_t order = predictive ? X.order[lane] : 0, wasted = tid < LW ? X.wasted[lane] : 0;
+			const int shift = tid < LW ? X.shift[lane] : 0;
+			uint32_t need = order;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const uint32_t t = __shfl_xor(need, o, 64);
+				need = t > need ? t : need;
+			}
+			const bool any_wide = __any(predictive && lane_wide);
+			const bool all24 = __all(!predictive || (flags & 4u));
+#define RESTORE(M) \
+	do { \
+		if (any_wide) restore_run<M, true, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
+		else if (all24) restore_run<M, false, true>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
+		else restore_run<M, false, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
+	} while (0)
+			if (need == 0) RESTORE(0);
+			else if (need <= 4) RESTORE(4);
+			else if (need <= 8) RESTORE(8);
+			else if (need <= 12) RESTORE(12);
+			else if (need <= 16) RESTORE(16);
+			else RESTORE(32);
+#undef RESTORE
+			return;
+		}
+	}
 	FaFrameCand cd;
 	if (live)
 		cd = cands[j];
@@ -553,7 +723,7 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 	}
 	// where the lane starts reading, in bits from the start of the input
 	uint64_t start_bit = (cd.pos + cd.hdr_bytes) * 8;
-	if (MODE == DEC_SUB && !(chained && only_c == 0)) {
+	if (SUBM && !(chained && only_c == 0)) {
 		if (live) {
 			start_bit = sub_start[(size_t)j * P.channels + only_c];
 			if (start_bit >= P.flac_bytes * 8) {   // DEC_NO_START: the frame ended in an earlier subframe
@@ -565,7 +735,7 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 	}
 	const uint64_t nwords = (P.flac_bytes + 3) / 4;
 	BitRd r;
-	r.wbase = MODE == DEC_SUB ? start_bit >> 5 : cd.pos >> 2;
+	r.wbase = SUBM ? start_bit >> 5 : cd.pos >> 2;
 	r.wg = flac_words + r.wbase;
 	r.nrel = nwords - r.wbase > 0xffffffffull ? 0xffffffffu : (uint32_t)(nwords - r.wbase);
 	// positions are 32-bit, relative to the frame's first word; a stream that goes on for more
@@ -612,11 +782,10 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 		const uint32_t t = __shfl_xor(bs_w, o, 64);
 		bs_w = t > bs_w ? t : bs_w;
 	}
-	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * LW;
 	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
 
-	const uint32_t c_first = MODE == DEC_SUB ? only_c : 0;
-	const uint32_t c_end = MODE == DEC_SUB ? only_c + 1 : P.channels - 1;
+	const uint32_t c_first = SUBM ? only_c : 0;
+	const uint32_t c_end = SUBM ? only_c + 1 : P.channels - 1;
 	for (uint32_t c = c_first; c < c_end; c++) {
 		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
 		if (MODE == DEC_SKIP && live)
@@ -705,6 +874,17 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 		const bool any_wide = __any(predictive && h.lane_wide);
 		const bool all24 = __all(!predictive || h.sbps <= 24);
 		const bool run = live && !r.err;
+		if constexpr (PIPE) {
+			if (tid < LW) {
+				X.order[lane] = h.order;
+				X.wasted[lane] = h.wasted;
+				X.shift[lane] = h.shift;
+				X.flags[lane] = (predictive ? 1u : 0u) | (h.lane_wide ? 2u : 0u) | (h.sbps <= 24 ? 4u : 0u);
+			}
+			__syncthreads();
+			decode_samples<0, false, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, &X);
+			continue;
+		}
 #define DECODE(M) \
 	do { \
 		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
@@ -739,7 +919,7 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 		}
 		return;
 	}
-	if (MODE == DEC_SUB && only_c + 1 != P.channels) {
+	if (SUBM && only_c + 1 != P.channels) {
 		// split: a subframe the walk got through cannot fail here (the same bits, the same checks).  Chained: this
 		// pass is the only one that looks at the subframe, so it says where the next one starts, or that the frame ends here
 		if (chained && have_frame && !live)
@@ -785,7 +965,7 @@ __global__ __launch_bounds__(DEC_LANES, 2) void k_dec_frames(FaDecParams P, cons
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
 	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st) \
 	{ \
-		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW, DEEP>), dim3(nwaves), dim3(DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
+		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW, DEEP>), dim3(nwaves), dim3(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
 	}
 
 #endif

