@@ -137,7 +137,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 	// (tools/dec_mode_probe.py, tools/bench_configs.py; frames stage, a lane per frame -> split): 16-bit stereo
 	// 256 frames 1.31 -> 1.01 ms, 6 460 frames 1.49 -> 1.20, 16 384 frames 1.61 -> 1.39; 24-bit stereo 14 063 frames
 	// 1.78 -> 1.46; eight channels of 24 bits 2 813 frames 5.9 -> 3.9; 67 500 stereo frames (135 000 subframes)
-	// 3.70 (32 frames per wave) -> 4.39.  Eight frames per wave up to 10 000 subframes, sixteen beyond.
+	// 3.70 (32 frames per wave) -> 4.39.  Eight frames per wave up to 4 096 subframes, sixteen beyond.
 	{
 		const char *mode = getenv("FLAC_AMD_DEC_MODE");
 		const uint64_t units = (uint64_t)max_frames * channels;
@@ -146,7 +146,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 			d->split = 1;
 		uint32_t lw = 4;
 		if (d->split)
-			lw = units <= 10000 ? 8 : 16;
+			lw = units <= 4096 ? 8 : 16;   // (4 096 stereo frames, frames stage: 0.68 ms at eight, 0.59 at sixteen)
 		else {
 			while (lw < 16 && (max_frames + lw - 1) / lw > 2048)
 				lw *= 2;
@@ -163,7 +163,9 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 		}
 		d->lw = lw;
 		// the walk of the split form: a lane per frame again, thin enough for the input pump to keep every lane fed
-		uint32_t slw = 8;
+		// (sixteen where the words per lane and block are few: 6 460 16-bit stereo frames 0.656 -> 0.643 ms, 16 384 frames
+		// 1.15 -> 1.07; 14 063 24-bit frames 1.46 -> 1.67)
+		uint32_t slw = (bits_per_sample <= 16 && channels == 2 && max_frames >= 6000) ? 16 : 8;
 		if (const char *env = getenv("FLAC_AMD_DEC_SKIP_LW")) {
 			const uint32_t v = (uint32_t)atoi(env);
 			if (v >= 1 && v <= 16 && (v & (v - 1)) == 0)

@@ -139,23 +139,30 @@ __device__ __forceinline__ uint32_t br_unary(BitRd &r)
 // k_dec_frames
 // ---------------------------------------------------------------------------------------------
 // MAXLW: the most frames a wave of this instance carries (the LDS it takes grows with it)
+// (every lane's ring starts at a multiple of its size in LDS: the plain blocks step through it with one and-or per word)
 template <int MAXLW, int RINGW>
-struct DecLds {
+struct __attribute__((aligned(RINGW * 4))) DecLds {
 	static constexpr int maxlw = MAXLW;
 	static constexpr int ring_words = RINGW;
 	static constexpr int run = RINGW > RING_WORDS_MIN ? DEC_RUN_BIG : DEC_RUN_MIN;
+	uint32_t ring[MAXLW][RINGW];             // input words per lane
 	int32_t q[FA_MAX_ORDER][MAXLW];          // predictor coefficients per lane
 	int32_t w[FA_MAX_ORDER][MAXLW];          // warm-up samples per lane
-	uint32_t ring[MAXLW][RINGW];             // input words per lane
 	int32_t out[run * MAXLW + 1];            // a run of decoded samples, [sample][lane]; the last word: for the lanes without a frame
 };
+typedef __attribute__((address_space(3))) const uint32_t LdsWord;
 
-// What the two waves of the pipelined form (DEC_PIPE) pass each other: the entropy wave leaves up to a run of values as
-// read from the stream (residuals, warm-up and verbatim samples, a constant) in res[0] and res[1] in turn, how many in
-// cnt[], and, once per subframe, what the restoring wave has to know about every lane's subframe.
+// What the two waves of the pipelined form (DEC_PIPE) pass each other: the entropy wave leaves up to a run of samples'
+// worth in res[0] and res[1] in turn, how many in cnt[], and, once per subframe, what the restoring wave has to know
+// about every lane's subframe.  A lane's words of a run are either values as read from the stream (residuals, warm-up
+// and verbatim samples, a constant: kf = PIPE_RAW) or, from the plain blocks, the 32 bits that start with each Rice
+// symbol, for the restoring wave to cut the symbol out of with all its lanes (kf = the Rice parameter).
+#define PIPE_RAW 0x80u
 template <int MAXLW, int RUN>
 struct PipeLds {
-	int32_t res[2][RUN * MAXLW + 1];        // [sample][lane]; the last word: for the lanes without a frame
+	int32_t res[2][RUN * MAXLW];            // [sample][lane]
+	int32_t dummy[DEC_BLOCK * MAXLW];       // where the lanes without a frame write
+	uint32_t kf[2][MAXLW];
 	uint32_t cnt[2];
 	uint32_t order[MAXLW];                  // predictor order; 0 where there is no predictor
 	uint32_t wasted[MAXLW];
@@ -267,12 +274,15 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	// samples below work_end need parsing; a constant subframe needs none
 	uint32_t work_end = (live && !r.err && h.kind != 0) ? bsf : 0;
 	// sample s of the run in hand goes to slot[s * sstride]; lanes that carry no frame all write to one spare word
+	// (PIPE: the stride is the instance's, so that a block's stores differ by constants; lanes without a frame write
+	// block after block over the same spare words)
 	int32_t *slot;
 	if constexpr (PIPE)
-		slot = tid < LW ? &X->res[0][tid] : &X->res[0][LDS::run * LDS::maxlw];
+		slot = tid < LW ? &X->res[0][tid] : &X->dummy[0];
 	else
 		slot = tid < LW ? &L.out[tid] : &L.out[LDS::run * LDS::maxlw];
-	const uint32_t sstride = tid < LW ? LW : 0u;
+	const uint32_t sstride = PIPE ? (uint32_t)LDS::maxlw : tid < LW ? LW : 0u;
+	const uint32_t bstride = tid < LW ? sstride : 0u;   // from block to block of a run
 	const uint32_t up = PIPE ? 0u : h.wasted;   // (the restoring wave shifts the wasted bits back in)
 	// the partition parameter(s) due at sample i (stream_decoder.c:2741-2767); the predictor is switched on with the first
 	auto read_part = [&](uint32_t i) __attribute__((always_inline)) {
@@ -377,6 +387,12 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			uint32_t cur = r.cur, nxt = r.nxt, rem = r.rem, wrel = r.wrel;
 			uint32_t n2 = r.ring[wrel & r.rmask], n3 = r.ring[(wrel + 1) & r.rmask];
 			uint32_t tmax = 0;
+			// where the word after n3 lies: a byte offset into the lane's ring that is let run on without wrapping (the
+			// words taken are counted off it afterwards), wrapped and turned into an LDS address by one and-or
+			constexpr uint32_t ring_bytes = LDS::ring_words * 4;
+			const uint32_t ring_lds = (uint32_t)(uintptr_t)(LdsWord *)r.ring;
+			const uint32_t at0 = (wrel + 1) * 4;
+			uint32_t at = at0;
 			// the history as it is now, in case the samples have to be done again: kept in the warm-up samples' place in
 			// LDS, which nobody reads any more once a partition parameter has been read
 			if (M > 0 && tid < LW) {
@@ -386,7 +402,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			}
 #pragma nounroll
 			for (uint32_t b0 = 0; b0 < nplain; b0 += DEC_BLOCK) {
-				int32_t *const bslot = slot + b0 * sstride;
+				int32_t *const bslot = slot + b0 * bstride;
 #pragma unroll
 				for (uint32_t s = 0; s < DEC_BLOCK; s++) {
 					const uint32_t win = __builtin_amdgcn_alignbit(cur, nxt, rem);
@@ -394,15 +410,21 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(win));
 					asm("v_add_u32_e64 %0, %1, %2 clamp" : "=v"(total) : "v"(z), "v"(kp1));
 					tmax = total > tmax ? total : tmax;
-					const int32_t left = (int32_t)rem - (int32_t)total;
-					const bool cross = left < 0;
-					cur = cross ? nxt : cur;
-					nxt = cross ? n2 : nxt;
-					n2 = cross ? n3 : n2;
-					wrel += cross ? 1u : 0u;
-					rem = (uint32_t)left & 31u;
-					n3 = r.ring[(wrel + 1) & r.rmask];
-					if (!SKIP) {
+					// the borrow of rem - total says whether the symbol ends in the next word; the selects take it as it comes
+					// out of the subtraction (the compiler spends a comparison and two more instructions on the same)
+					uint32_t left, step;
+					uint64_t cross;
+					asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(left), "=s"(cross) : "v"(rem), "v"(total));
+					asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(cur) : "v"(cur), "v"(nxt), "s"(cross));
+					asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nxt) : "v"(nxt), "v"(n2), "s"(cross));
+					asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(n2) : "v"(n2), "v"(n3), "s"(cross));
+					asm("v_cndmask_b32_e64 %0, 0, 4, %1" : "=v"(step) : "s"(cross));
+					rem = left & 31u;
+					at += step;
+					n3 = *(LdsWord *)(uintptr_t)((at & (ring_bytes - 1)) | ring_lds);
+					if (PIPE)
+						bslot[s * sstride] = (int32_t)win;   // (the restoring wave cuts the symbol out)
+					else if (!SKIP) {
 						const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 32u - total, k);
 						const uint32_t uf = (z << k) | lsbs;
 						const int32_t res = (int32_t)(uf >> 1) ^ __builtin_amdgcn_sbfe((int32_t)uf, 0, 1);
@@ -410,6 +432,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					}
 				}
 			}
+			wrel += (at - at0) >> 2;
 			if (!__any(!idle && tmax > 32)) {
 				if (!idle) {
 					r.cur = cur;
@@ -417,10 +440,14 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 					r.rem = rem;
 					r.wrel = wrel;
 				}
+				if constexpr (PIPE) {
+					if (tid < LW)
+						X->kf[hand][lane] = idle ? PIPE_RAW : k;
+				}
 				if (!SKIP && __any(idle && tid < LW)) {
 					if (idle) {
 						for (uint32_t s = 0; s < nplain; s++)
-							slot[s * sstride] = (int32_t)((uint32_t)h.constant << up);
+							slot[s * bstride] = (int32_t)((uint32_t)h.constant << up);
 					}
 				}
 				block_done = true;
@@ -436,6 +463,10 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 		uint32_t nout = nplain;
 		if (!block_done) {
 		nout = DEC_BLOCK;
+		if constexpr (PIPE) {
+			if (tid < LW)
+				X->kf[hand][lane] = PIPE_RAW;
+		}
 		// (a stream that ends early feeds zeros, which no plain block gets through: the end is looked for here)
 		if (br_pos(r) > r.bend) {
 			r.err = true;
@@ -522,7 +553,7 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				X->cnt[hand] = i0 + nout < bs_w ? nout : bs_w - i0;
 			__syncthreads();
 			hand ^= 1u;
-			slot = tid < LW ? &X->res[hand][tid] : &X->res[hand][LDS::run * LDS::maxlw];
+			slot = tid < LW ? &X->res[hand][tid] : &X->dummy[0];
 		} else if (!SKIP) {
 			// the samples go out with all 64 threads along memory order
 			const uint32_t nblk = (i0 + nout < bs_w ? nout : bs_w - i0) * LW;
@@ -530,6 +561,142 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 				plane[(size_t)i0 * LW + e] = L.out[e];
 		}
 		i0 += nout;
+	}
+}
+
+// Rice symbols that were handed over as they lie in the stream: thread t looks after the words of lane t mod 16,
+// four samples at a time (bitreader.c:775: zeros up to the stop bit, then the parameter's worth of low bits; zigzag)
+template <typename LDS, typename PX>
+__device__ __forceinline__ void pipe_cut_symbols(PX &X, uint32_t hand, uint32_t n, uint32_t tid)
+{
+	constexpr uint32_t xstride = LDS::maxlw;
+	static_assert(DEC_LANES % xstride == 0, "a thread stays with one lane's words");
+	const uint32_t kf = X.kf[hand][tid & (xstride - 1)];
+	if (!__all(kf & PIPE_RAW)) {
+		const uint32_t k = kf & 31u;
+		const bool mine = !(kf & PIPE_RAW);
+		const uint32_t lim = n * xstride;
+		// eight words at a time, all requested before the first is used (an LDS round trip costs a lone wave as much
+		// as twenty instructions)
+		for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
+			uint32_t win[8];
+#pragma unroll
+			for (uint32_t u = 0; u < 8; u++)
+				win[u] = e0 + u * DEC_LANES < lim ? (uint32_t)X.res[hand][e0 + u * DEC_LANES] : 0u;
+#pragma unroll
+			for (uint32_t u = 0; u < 8; u++) {
+				const uint32_t z = (uint32_t)__clz((int)win[u]);
+				const uint32_t lsbs = __builtin_amdgcn_ubfe(win[u], 31u - z - k, k);
+				const uint32_t uf = (z << k) | lsbs;
+				const int32_t v = (int32_t)(uf >> 1) ^ -(int32_t)(uf & 1u);
+				if (mine && e0 + u * DEC_LANES < lim)
+					X.res[hand][e0 + u * DEC_LANES] = v;
+			}
+		}
+	}
+}
+
+// The restoring wave where no lane's sum needs 64 bits: four threads to a subframe, thread t of the four holding taps
+// T t .. T t + T - 1 and the samples they multiply.  A sample costs T multiply-adds, two adds across the four (after
+// which each has the whole sum; 32-bit sums wrap the same in any order), shift, add, and one move that hands every
+// thread's oldest sample to the next thread while the first keeps the new one: ten instructions at order 12 where one
+// thread per subframe issues twenty, and a lone wave issues a dependent instruction only every nine cycles.
+// The four sit in the four banks of a row of sixteen lanes (lane = 16 r + 4 t + i for subframe 4 r + i), so that
+// "the next thread" is a shift by four lanes and "not the first" is a bank mask.  The samples stay as they are in LDS
+// ([sample][lane], the instance's stride); the wasted bits are shifted back in on the way out.
+template <int T, bool MUL24, typename LDS, typename PX>
+__device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t need)
+{
+	static_assert(LDS::maxlw == 16 && DEC_LANES == 64, "four threads per subframe, sixteen subframes");
+	constexpr uint32_t xstride = LDS::maxlw;
+	const uint32_t f = ((tid >> 4) << 2) | (tid & 3u), t = (tid >> 2) & 3u;
+	const bool have = f < LW;
+	const uint32_t fl = have ? f : 0;
+	const bool predictive = have && (X.flags[fl] & 1u);
+	const uint32_t order = predictive ? X.order[fl] : 0;
+	const int shift = have ? X.shift[fl] : 0;
+	// (for the way out, where thread t looks after column t mod 16)
+	const uint32_t col = tid & (xstride - 1);
+	const uint32_t col_wasted = col < LW ? X.wasted[col] : 0;
+	int32_t q[T], h[T];
+#pragma unroll
+	for (int u = 0; u < T; u++) {
+		q[u] = 0;
+		h[u] = 0;
+	}
+	auto step = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
+		int32_t part;
+		if (MUL24) {
+			asm("v_mul_i32_i24 %0, %1, %2" : "=v"(part) : "v"(q[T - 1]), "v"(h[T - 1]));
+#pragma unroll
+			for (int u = T - 2; u >= 0; u--)
+				asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(part) : "v"(q[u]), "v"(h[u]), "v"(part));
+		} else {
+			part = q[T - 1] * h[T - 1];
+#pragma unroll
+			for (int u = T - 2; u >= 0; u--)
+				part += q[u] * h[u];
+		}
+		part += __builtin_amdgcn_update_dpp(0, part, 0x124, 0xf, 0xf, true);   // row_ror:4
+		part += __builtin_amdgcn_update_dpp(0, part, 0x128, 0xf, 0xf, true);   // row_ror:8
+		const int32_t v = (int32_t)((uint32_t)res + (uint32_t)(part >> shift));
+		// row_shr:4, written in banks 1 to 3 only: every thread's oldest sample to the next of the four, the first keeps the new one
+		const int32_t in = __builtin_amdgcn_update_dpp(v, h[T - 1], 0x114, 0xf, 0xe, false);
+#pragma unroll
+		for (int u = T - 1; u > 0; u--)
+			h[u] = h[u - 1];
+		h[0] = in;
+		return v;
+	};
+	uint32_t hand = 0;
+	for (uint32_t i0 = 0; i0 < bs_w;) {
+		__syncthreads();
+		const uint32_t n = X.cnt[hand];
+		pipe_cut_symbols<LDS>(X, hand, n, tid);
+		const int32_t *src = have ? &X.res[hand][f] : &X.dummy[0];
+#pragma nounroll
+		for (uint32_t b0 = 0; b0 < n; b0 += DEC_BLOCK) {
+			const int32_t *bsrc = src + (have ? b0 * xstride : 0u);
+			int32_t *bslot = have ? &L.out[b0 * xstride + f] : &X.dummy[0];
+			// (all of the block's values first: a load between the stores would be waited for sample by sample)
+			int32_t rv[DEC_BLOCK];
+#pragma unroll
+			for (uint32_t s = 0; s < DEC_BLOCK; s++)
+				rv[s] = bsrc[s * xstride];
+			if (i0 + b0 <= need) {
+				// a block in which some subframe's warm-up may end
+#pragma unroll
+				for (uint32_t s = 0; s < DEC_BLOCK; s++) {
+					if (predictive && i0 + b0 + s == order) {
+#pragma unroll
+						for (int u = 0; u < T; u++)
+							q[u] = T * t + u < order ? L.q[T * t + u][fl] : 0;
+					}
+					bslot[s * xstride] = step(rv[s]);
+				}
+			} else {
+#pragma unroll
+				for (uint32_t s = 0; s < DEC_BLOCK; s++)
+					bslot[s * xstride] = step(rv[s]);
+			}
+		}
+		if (col < LW) {
+			const uint32_t lim = n * xstride;
+			for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
+				int32_t v[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++)
+					v[u] = e0 + u * DEC_LANES < lim ? L.out[e0 + u * DEC_LANES] : 0;
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					const uint32_t e = e0 + u * DEC_LANES;
+					if (e < lim)
+						plane[(size_t)(i0 + (e / xstride)) * LW + col] = (int32_t)((uint32_t)v[u] << col_wasted);
+				}
+			}
+		}
+		i0 += n;
+		hand ^= 1u;
 	}
 }
 
@@ -549,8 +716,9 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 		hist[j] = 0;
 	}
 	const uint32_t lane = tid < (uint32_t)LDS::maxlw ? tid : 0;
-	const uint32_t rstride = tid < LW ? LW : 0u, rbase = tid < LW ? tid : (uint32_t)(LDS::run * LDS::maxlw);
-	int32_t *const slot = &L.out[rbase];
+	constexpr uint32_t xstride = LDS::maxlw;   // of the exchange buffers
+	const uint32_t rstride = tid < LW ? LW : 0u;
+	int32_t *const slot = &L.out[tid < LW ? tid : (uint32_t)(LDS::run * LDS::maxlw)];
 	auto step = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
 		int32_t v = res;
 		if (M > 0) {
@@ -594,11 +762,17 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 	for (uint32_t i0 = 0; i0 < bs_w;) {
 		__syncthreads();
 		const uint32_t n = X.cnt[hand];
-		const int32_t *src = &X.res[hand][rbase];
+		pipe_cut_symbols<LDS>(X, hand, n, tid);
+		const int32_t *src = tid < LW ? &X.res[hand][tid] : &X.dummy[0];
 #pragma nounroll
 		for (uint32_t b0 = 0; b0 < n; b0 += DEC_BLOCK) {
-			const int32_t *bsrc = src + b0 * rstride;
+			const int32_t *bsrc = src + (tid < LW ? b0 * xstride : 0u);
 			int32_t *bslot = slot + b0 * rstride;
+			// (all of the block's values first: a load between the stores would be waited for sample by sample)
+			int32_t rv[DEC_BLOCK];
+#pragma unroll
+			for (uint32_t s = 0; s < DEC_BLOCK; s++)
+				rv[s] = bsrc[s * xstride];
 			if (M > 0 && i0 + b0 <= need) {
 				// a block in which some lane's warm-up may end
 #pragma unroll
@@ -608,12 +782,12 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 						for (int j = 0; j < M; j++)
 							q[j] = (uint32_t)j < order ? L.q[j][lane] : 0;
 					}
-					bslot[s * rstride] = (int32_t)((uint32_t)step(bsrc[s * rstride]) << wasted);
+					bslot[s * rstride] = (int32_t)((uint32_t)step(rv[s]) << wasted);
 				}
 			} else {
 #pragma unroll
 				for (uint32_t s = 0; s < DEC_BLOCK; s++)
-					bslot[s * rstride] = (int32_t)((uint32_t)step(bsrc[s * rstride]) << wasted);
+					bslot[s * rstride] = (int32_t)((uint32_t)step(rv[s]) << wasted);
 			}
 		}
 		const uint32_t nblk = n * LW;
@@ -699,18 +873,26 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 			}
 			const bool any_wide = __any(predictive && lane_wide);
 			const bool all24 = __all(!predictive || (flags & 4u));
-#define RESTORE(M) \
+#define RESTORE(M, WIDE) restore_run<M, WIDE, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need)
+#define RESTORE_QUAD(T) \
 	do { \
-		if (any_wide) restore_run<M, true, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
-		else if (all24) restore_run<M, false, true>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
-		else restore_run<M, false, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need); \
+		if (all24) restore_run_quad<T, true>(L, X, plane, LW, tid, bs_w, need); \
+		else restore_run_quad<T, false>(L, X, plane, LW, tid, bs_w, need); \
 	} while (0)
-			if (need == 0) RESTORE(0);
-			else if (need <= 4) RESTORE(4);
-			else if (need <= 8) RESTORE(8);
-			else if (need <= 12) RESTORE(12);
-			else if (need <= 16) RESTORE(16);
-			else RESTORE(32);
+			if (need == 0) RESTORE(0, false);
+			else if (!any_wide) {
+				if (need <= 4) RESTORE_QUAD(1);
+				else if (need <= 8) RESTORE_QUAD(2);
+				else if (need <= 12) RESTORE_QUAD(3);
+				else if (need <= 16) RESTORE_QUAD(4);
+				else RESTORE_QUAD(8);
+			}
+			else if (need <= 4) RESTORE(4, true);
+			else if (need <= 8) RESTORE(8, true);
+			else if (need <= 12) RESTORE(12, true);
+			else if (need <= 16) RESTORE(16, true);
+			else RESTORE(32, true);
+#undef RESTORE_QUAD
 #undef RESTORE
 			return;
 		}
