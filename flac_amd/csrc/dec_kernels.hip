@@ -742,11 +742,12 @@ void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaS
 		const uint32_t walk_waves = (P.max_frames + P.skip_lw - 1) / P.skip_lw, sub_waves = groups * P.channels;
 		P.run = walk_waves <= deep_waves ? 64u : shallow_run;
 		(walk_waves <= deep_waves ? fa_dec_frames_skip16d : fa_dec_frames_skip16)(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, walk_waves, 0xffffffffu, st);
-		// Two waves per subframe group (one reads, one restores) while all of them find room on the chip at once: 33 KB
-		// of LDS and 2 x 187 registers per workgroup, four to a CU.  Measured (frames stage, one wave -> two): 16-bit
-		// stereo 256 frames 0.63 -> 0.49 ms, 6 460 frames 0.85 -> 0.73; beyond what fits at once (24-bit stereo
-		// 14 063 frames, 1 758 groups, shallow ring) 1.38 -> 1.61, so those keep one wave.
-		uint32_t pipe_groups = 256 * 4;
+		// Two waves per subframe group (one reads, one restores) while all of them find room on the chip at once: 35 KB
+		// of LDS per workgroup with the deep ring, four to a CU; with the shallow ring the registers (147 per thread)
+		// allow six.  Measured (frames stage, one wave -> two): 16-bit stereo 256 frames 0.63 -> 0.50 ms, 6 460 frames
+		// 0.85 -> 0.65; eight channels of 24 bits, 2 813 frames (1 408 groups) 2.70 -> 2.38; beyond what fits at once
+		// (24-bit stereo 14 063 frames, 1 758 groups) 1.46 -> 1.63, so those keep one wave.
+		uint32_t pipe_groups = 256 * 6;
 		if (const char *env = getenv("FLAC_AMD_DEC_PIPE"))
 			pipe_groups = (uint32_t)atoi(env);
 		if (sub_waves <= pipe_groups) {

@@ -837,11 +837,12 @@ __device__ __forceinline__ uint32_t assignment_argmin(const FaPlan *p /* L,R,M,S
 	return ca;
 }
 
-__global__ void k_decide(FaEncParams P, FaBatch B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out)
+__global__ void k_decide(FaEncParams P, FaBatch B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, unsigned long long *tickets)
 {
 	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= B.nframes)
 		return;
+	tickets[f] = 0;   // nothing known yet about where frame f goes (k_pack_frame)
 	uint32_t ca = 0;
 	if (P.do_ms) {
 		if (P.loose_ms) {
@@ -985,9 +986,10 @@ void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stat
 	hipLaunchKernelGGL(k_lpc, dim3((nsub + LPC_LANES - 1) / LPC_LANES), dim3(LPC_LANES), 0, st, P, B, stats, autoc, cands, coefs);
 }
 
-void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st)
+void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, unsigned long long *tickets,
+                      hipStream_t st)
 {
-	hipLaunchKernelGGL(k_decide, dim3((B.nframes + 255) / 256), dim3(256), 0, st, P, B, plans, assign, loose_out);
+	hipLaunchKernelGGL(k_decide, dim3((B.nframes + 255) / 256), dim3(256), 0, st, P, B, plans, assign, loose_out, tickets);
 }
 
 void fa_launch_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets, hipStream_t st)

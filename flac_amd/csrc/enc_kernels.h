@@ -24,9 +24,14 @@ void fa_launch_search_wave_split(const FaEncParams &P, const FaBatch &B, const v
 void fa_launch_search_wave(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaLpcCand *cands,
                            const int32_t *coefs, FaPlan *plans, unsigned long long sig_list, uint32_t nsel, unsigned long long wide_list, uint32_t nwide,
                            hipStream_t st);
-void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, hipStream_t st);
-void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
-                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st);
+// tickets: one word per frame, cleared here for the frame writer's placement (see fa_launch_pack)
+void fa_launch_decide(const FaEncParams &P, const FaBatch &B, const FaPlan *plans, uint32_t *assign, uint32_t *loose_out, unsigned long long *tickets,
+                      hipStream_t st);
+// Returns true when the frames went straight to their places in `out` (sizes in frame_bytes, places in offsets[0 .. nframes]):
+// the streams k_pack_frame writes.  Otherwise they are in their slots, for fa_launch_scan and fa_launch_compact.
+bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, uint8_t *out, uint64_t out_capacity,
+                    uint64_t *offsets, unsigned long long *tickets, hipStream_t st);
 void fa_launch_scan(const uint32_t *frame_bytes, uint32_t n, uint64_t *offsets, hipStream_t st);
 void fa_launch_compact(const FaEncParams &P, const FaBatch &B, const uint32_t *slots, const uint32_t *frame_bytes, const uint64_t *offsets,
                        uint8_t *out, uint64_t out_capacity, uint32_t *errflag, hipStream_t st);

@@ -747,6 +747,7 @@ struct PqShared {
 	int32_t q[4][FA_MAX_ORDER];
 	uint4 head[4];   // FaPlan's first words: bits | type, order, precision, shift | part_order, rice2, wide, - | constant
 	uint2 stat[4];   // wasted, subframe bps
+	uint64_t place;  // bytes in front of the frame in the output
 };
 
 // One written subframe, the same in every thread.
@@ -892,13 +893,61 @@ __device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint
 	}
 }
 
+// Where a frame goes in the output is the sum of the sizes of the frames before it, and a frame's size is known well
+// before its bits are (after the scan over the code lengths).  Every workgroup publishes its size in its ticket at that
+// point (PQ_SIZE), and when its bits are ready one wave looks back over the tickets in front of it, 64 at a time,
+// adding sizes until it meets a ticket that already holds a finished sum (PQ_SUM: that frame's own end), and then
+// publishes its own.  Workgroups start in order and none waits before it has published its size, so the wait ends.
+// This is what lets the frame leave the LDS window straight for its place: no slots, no scan and copy kernels behind.
+#define PQ_SIZE (1ull << 62)
+#define PQ_SUM (2ull << 62)
+#define PQ_VALUE ((1ull << 62) - 1)
+// WAIT = false: one look at the 64 tickets in front, no waiting; false if that does not settle it (nothing is published then).
+template <bool WAIT>
+__device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f, uint32_t size, uint32_t lane, uint64_t &place)
+{
+	uint64_t before = 0;
+	int64_t at = (int64_t)f - 1;
+	while (at >= 0) {
+		const int64_t i = at - (int64_t)lane;
+		// (in front of the first frame: a finished sum of nothing)
+		const uint64_t t = i >= 0 ? __hip_atomic_load(&tickets[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PQ_SUM;
+		const uint64_t is_sum = __ballot((t >> 62) == 2), is_none = __ballot((t >> 62) == 0);
+		// the tickets that count: up to and including the nearest finished sum
+		const uint32_t nearest = is_sum ? (uint32_t)__ffsll((unsigned long long)is_sum) - 1u : 63u;
+		const uint64_t upto = nearest == 63u ? ~0ull : (2ull << nearest) - 1ull;
+		if (is_none & upto) {
+			if (!WAIT)
+				return false;
+			__builtin_amdgcn_s_sleep(2);
+			continue;
+		}
+		if (!WAIT && !is_sum)
+			return false;
+		uint64_t v = lane <= nearest ? (t & PQ_VALUE) : 0;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			v += __shfl_xor(v, o, 64);
+		before += v;
+		if (is_sum)
+			break;
+		at -= 64;
+	}
+	if (lane == 0)
+		__hip_atomic_store(&tickets[f], PQ_SUM | (before + size), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	place = before;
+	return true;
+}
+
 #ifndef PQ_WAVES
 #define PQ_WAVES 4   // workgroups per CU (one wave of each per SIMD)
 #endif
+// tickets: not null = the frame goes to its place in `out` (pq_place; its place also into offsets[f]), else into its slot
 template <int HIST>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PQ_WAVES, PQ_WAVES)))
 void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaPlan *__restrict__ plans,
-                  const uint32_t *__restrict__ assign, uint32_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, uint32_t *errflag)
+                  const uint32_t *__restrict__ assign, uint32_t *__restrict__ slots, uint32_t *__restrict__ frame_bytes, uint32_t *errflag,
+                  uint8_t *__restrict__ out, uint64_t out_capacity, uint64_t *__restrict__ offsets, unsigned long long *tickets)
 {
 	__shared__ PqShared<HIST> S;
 	const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
@@ -1037,7 +1086,26 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 			atomicOr(errflag, 1u);
 			frame_bytes[f] = 0;
 		}
+		if (tickets && wv == 0) {
+			uint64_t before = 0;
+			pq_place<true>(tickets, f, 0, lane, before);
+			if (lane == 0) {
+				offsets[f] = before;
+				if (f == B.nframes - 1)
+					offsets[B.nframes] = before;
+			}
+		}
 		return;
+	}
+	// The place: tried without waiting as soon as the size is known (a wait at the end of the frame is time in which the
+	// workgroup holds its share of the CU for nothing; a sum published early also spares the frames behind their wait),
+	// again after the codes are out, and waited for only before the bits leave.
+	bool placed = false;
+	uint64_t place = 0;
+	if (tickets && wv == 0) {
+		if (lane == 0)
+			__hip_atomic_store(&tickets[f], PQ_SIZE | (uint64_t)(nbytes + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		placed = pq_place<false>(tickets, f, nbytes + 2, lane, place);
 	}
 	uint32_t *W = S.u.W;
 	for (uint32_t i = tid; i < (total_words + 2 + 3) / 4; i += FA_THREADS)
@@ -1092,12 +1160,61 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 			if (4 * i < hn)
 				pq_emit(W, 32 * i, (uint32_t)(hw[i >> 1] >> ((i & 1u) ? 0 : 32)));   // (the bytes behind the header read as zero)
 	}
+	if (tickets && wv == 0 && !placed)
+		placed = pq_place<false>(tickets, f, nbytes + 2, lane, place);
 	__syncthreads();
 
 	// ---- CRC-16 over everything so far (stream_encoder.c:2890-2900), then out to the frame's slot ----
 	const uint32_t crc16 = window_crc16(W, S.crc_tables, S.crcs, nbytes);
 	if (tid == 0)
 		pq_emit(W, nbytes * 8, crc16 << 16);
+	if (tickets) {
+		// ---- straight to the frame's place: bytes up to a 16-byte boundary of the output, whole vectors, the rest ----
+		if (wv == 0) {
+			if (!placed)
+				pq_place<true>(tickets, f, nbytes + 2, lane, place);
+			if (lane == 0) {
+				S.place = place;
+				offsets[f] = place;
+				if (f == B.nframes - 1)
+					offsets[B.nframes] = place + nbytes + 2;
+				frame_bytes[f] = nbytes + 2;
+			}
+		}
+		__syncthreads();
+		const uint64_t before = S.place;
+		const uint32_t total = nbytes + 2;
+		if (before + total > out_capacity) {
+			if (tid == 0)
+				atomicOr(errflag, 2u);
+			return;
+		}
+		uint8_t *dst = out + before;
+		const uint32_t head = umin32((uint32_t)((16 - ((uintptr_t)dst & 15)) & 15), total);
+		const uint32_t nvec = (total - head) / 16, tail0 = head + 16 * nvec;
+		// byte k of the frame is byte k mod 4, counted from the top, of window word k / 4
+		if (tid < head)
+			dst[tid] = (uint8_t)(W[tid >> 2] >> (24 - 8 * (tid & 3)));
+		if (tid >= FA_THREADS - 16 && tail0 + (tid - (FA_THREADS - 16)) < total) {
+			const uint32_t k = tail0 + (tid - (FA_THREADS - 16));
+			dst[k] = (uint8_t)(W[k >> 2] >> (24 - 8 * (k & 3)));
+		}
+		const uint32_t sh = head & 3, w0 = head >> 2;
+		for (uint32_t i = tid; i < nvec; i += FA_THREADS) {
+			uint32_t w[5];
+#pragma unroll
+			for (int j = 0; j < 5; j++)
+				w[j] = W[w0 + 4 * i + j];
+			uint4 v;
+			// (a funnel shift by 32 - 8 sh bits; by nothing when the places agree modulo four)
+			v.x = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[0], w[1], 32 - 8 * sh) : w[0]);
+			v.y = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[1], w[2], 32 - 8 * sh) : w[1]);
+			v.z = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[2], w[3], 32 - 8 * sh) : w[2]);
+			v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[3], w[4], 32 - 8 * sh) : w[3]);
+			((uint4 *)(dst + head))[i] = v;
+		}
+		return;
+	}
 	__syncthreads();
 	for (uint32_t i = tid; i < (total_words + 3) / 4; i += FA_THREADS) {
 		uint4 v = ((const uint4 *)W)[i];
@@ -1127,8 +1244,9 @@ static bool pack_frame_eligible(const FaEncParams &P, const FaBatch &B)
 	return P.slot_bytes / 4 <= PQ_CAPW;
 }
 
-void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
-                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, hipStream_t st)
+bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, const FaSubStat *stats, const FaPlan *plans, const uint32_t *assign,
+                    uint32_t *slots, uint32_t *frame_bytes, uint32_t *errflag, unsigned long long *stamps, uint8_t *out, uint64_t out_capacity,
+                    uint64_t *offsets, unsigned long long *tickets, hipStream_t st)
 {
 	const dim3 block(FA_THREADS);
 	const bool narrow = fa_narrow_only(P);
@@ -1143,16 +1261,18 @@ void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 		const uint32_t nfull = B.nframes;   // (a short last block is one partition: it fits too)
 		if (!generic_only && nfull && pack_frame_eligible(P, B)) {
 			const dim3 grid(nfull);
+			// FLAC_AMD_PACK=slots: k_pack_frame into the slots, scan and copy kernels behind it (for comparisons)
+			unsigned long long *tk = (mode && !strcmp(mode, "slots")) ? nullptr : tickets;
 			switch (hist) {
-			case 4: hipLaunchKernelGGL(k_pack_frame<4>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
-			case 12: hipLaunchKernelGGL(k_pack_frame<12>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
-			default: hipLaunchKernelGGL(k_pack_frame<32>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag); break;
+			case 4: hipLaunchKernelGGL(k_pack_frame<4>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, out, out_capacity, offsets, tk); break;
+			case 12: hipLaunchKernelGGL(k_pack_frame<12>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, out, out_capacity, offsets, tk); break;
+			default: hipLaunchKernelGGL(k_pack_frame<32>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, out, out_capacity, offsets, tk); break;
 			}
-			first = nfull;
+			return tk != nullptr;
 		}
 	}
 	if (first >= B.nframes)
-		return;
+		return false;
 	const dim3 grid(B.nframes - first);
 #define PACK_LAUNCH(H, N) \
 	do { \
@@ -1165,4 +1285,5 @@ void fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 	default: if (narrow) PACK_LAUNCH(32, true); else PACK_LAUNCH(32, false); break;
 	}
 #undef PACK_LAUNCH
+	return false;
 }

@@ -116,3 +116,58 @@ def test_both_forms_against_the_oracle_at_smaller_block_sizes(bs):
             want, _ = O.encode_frames(op, pcm)
             for form in ("generic", "frame"):
                 assert encode(p, pcm, form) == list(want), (sname, name, bs, form)
+
+
+def _encode_device(p, pcm16, nframes, shift, capacity=None, form=None):
+    """Frames of one batch from device memory, the output starting `shift` bytes into its buffer."""
+    import torch
+    import flac_amd
+    if form:
+        os.environ["FLAC_AMD_PACK"] = form
+    else:
+        os.environ.pop("FLAC_AMD_PACK", None)
+    try:
+        dev = torch.device("cuda", 0)
+        enc = flac_amd.Encoder(p, device=0, max_frames=nframes)
+        try:
+            cap = enc.max_output_bytes(nframes) if capacity is None else capacity
+            src = torch.from_numpy(pcm16).to(dev)
+            out = torch.full((enc.max_output_bytes(nframes) + 64,), 0xA5, dtype=torch.uint8, device=dev)
+            sizes = torch.zeros(nframes, dtype=torch.int32, device=dev)
+            offs = torch.zeros(nframes + 1, dtype=torch.int64, device=dev)
+            enc.encode_device(src.data_ptr(), 2, pcm16.shape[0], out.data_ptr() + shift, cap, sizes.data_ptr(), offs.data_ptr())
+            torch.cuda.synchronize()
+            enc.status()
+            return out.cpu().numpy(), sizes.cpu().numpy(), offs.cpu().numpy()
+        finally:
+            enc.close()
+    finally:
+        os.environ.pop("FLAC_AMD_PACK", None)
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3, 7, 13])
+def test_frames_placed_directly_are_the_frames_copied_from_slots(shift):
+    """k_pack_frame puts every frame straight where it belongs (sizes summed over the frames in front by a look-back
+    over per-frame tickets); FLAC_AMD_PACK=slots keeps the slots, the scan and the copy.  Same bytes, sizes and places
+    for 1 500 frames (more than the chip holds workgroups at once), wherever the output starts; not a byte outside."""
+    import flac_amd
+    from flac_amd import synth
+    nframes = 1500
+    p = flac_amd.preset(8, 2, 16, 44100, 4096)
+    pcm = synth.synth_pcm(wide_samples=nframes * 4096 - 1000, sample_rate=44100, channels=2, bits_per_sample=16, seed=77).astype(np.int16)
+    a, sa, oa = _encode_device(p, pcm, nframes, shift, form="slots")
+    b, sb, ob = _encode_device(p, pcm, nframes, shift)
+    assert np.array_equal(sa, sb) and np.array_equal(oa, ob)
+    total = int(ob[nframes])
+    assert total == int(sb.sum()) and np.array_equal(ob[:-1], np.concatenate(([0], np.cumsum(sb[:-1]))))
+    assert np.array_equal(a[shift:shift + total], b[shift:shift + total])
+    assert (b[:shift] == 0xA5).all() and (b[shift + total:] == 0xA5).all()
+
+
+def test_direct_placement_reports_an_output_that_is_too_small():
+    import flac_amd
+    from flac_amd import synth
+    p = flac_amd.preset(8, 2, 16, 44100, 4096)
+    pcm = synth.synth_pcm(wide_samples=64 * 4096, sample_rate=44100, channels=2, bits_per_sample=16, seed=5).astype(np.int16)
+    with pytest.raises(flac_amd.FlacAmdError):
+        _encode_device(p, pcm, 64, 0, capacity=100000)
