@@ -23,6 +23,7 @@ struct flacamd_decoder {
 	uint32_t max_streams;
 	FaStream *streams;
 	uint32_t *block_counts;
+	FaSubInfo *subinfo;             // one record per (frame, channel) once flacamd_decoder_enable_subframe_info asked for them
 	uint64_t *crc_ahead;            // per header: the CRC pass that runs beside the frame decoder leaves its guess and verdict here
 	hipStream_t side;               // that pass and the clearing of the output run here, between ev_fork and ev_join
 	hipEvent_t ev_fork, ev_join;
@@ -49,6 +50,7 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipFree(d->streams);
 	(void)hipFree(d->block_counts);
 	(void)hipFree(d->crc_ahead);
+	(void)hipFree(d->subinfo);
 	if (d->side)
 		(void)hipStreamDestroy(d->side);
 	if (d->ev_fork)
@@ -268,6 +270,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.run = 16;
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
+	P.subinfo = d->subinfo;
 	const bool prof = d->profiling != 0;
 	int evi = 0;
 #define STAGE_MARK() \
@@ -306,6 +309,43 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 		d->have_times = 1;
 	d->last_stream = st;
 	HIP_TRY(hipGetLastError());
+	return FLACAMD_OK;
+}
+
+static_assert(sizeof(FaSubInfo) == sizeof(flacamd_subframe_info), "subframe record layout");
+
+extern "C" int flacamd_decoder_enable_subframe_info(flacamd_decoder *d, int on)
+{
+	if (!d)
+		return fa_fail(FLACAMD_E_INVALID, "null decoder");
+	HIP_TRY(hipSetDevice(d->device));
+	if (d->last_stream || d->subinfo)
+		HIP_TRY(hipDeviceSynchronize());   // (a decode in flight may be writing records)
+	if (on && !d->subinfo) {
+		const size_t bytes = sizeof(FaSubInfo) * (size_t)d->max_frames * d->channels;
+		hipError_t e = hipMalloc((void **)&d->subinfo, bytes);
+		if (e != hipSuccess) {
+			d->subinfo = nullptr;
+			return fa_fail(FLACAMD_E_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+		}
+	} else if (!on && d->subinfo) {
+		(void)hipFree(d->subinfo);
+		d->subinfo = nullptr;
+	}
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_subframe_info(flacamd_decoder *d, uint32_t first_frame, uint32_t nframes, flacamd_subframe_info *out)
+{
+	if (!d || !out)
+		return fa_fail(FLACAMD_E_INVALID, "null argument");
+	if (!d->subinfo)
+		return fa_fail(FLACAMD_E_INVALID, "subframe records were not asked for (flacamd_decoder_enable_subframe_info)");
+	if ((uint64_t)first_frame + nframes > d->max_frames)
+		return fa_fail(FLACAMD_E_INVALID, "frames [%u, %u) are beyond the decoder's capacity of %u", first_frame, first_frame + nframes, d->max_frames);
+	HIP_TRY(hipSetDevice(d->device));
+	HIP_TRY(hipStreamSynchronize(d->last_stream));
+	HIP_TRY(hipMemcpy(out, d->subinfo + (size_t)first_frame * d->channels, sizeof(FaSubInfo) * (size_t)nframes * d->channels, hipMemcpyDeviceToHost));
 	return FLACAMD_OK;
 }
 

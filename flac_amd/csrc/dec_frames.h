@@ -184,7 +184,7 @@ struct Pump {
 // what a lane knows about its current subframe once the subframe header is parsed
 struct SubHdr {
 	uint32_t kind;      // 0 constant, 1 verbatim, 2 fixed, 3 lpc
-	uint32_t order, wasted, sbps;
+	uint32_t order, wasted, sbps, prec;
 	uint32_t po, plen, pesc, psize;
 	int shift;
 	bool lane_wide;
@@ -251,9 +251,10 @@ __device__ __forceinline__ void pump_service(Pump &pm, BitRd &r, LDS &L, uint32_
 // PX = PipeLds: the values go to the restoring wave as they are (M is 0), a run at a time, instead of to the planes.
 template <int M, bool WIDE, bool MUL24, bool SKIP = false, typename LDS, typename PX = NoPipe>
 __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr &h, LDS &L, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w,
-                                               uint32_t bsf, bool live, uint64_t nwords, uint32_t run_len, PX *X = nullptr)
+                                               uint32_t bsf, bool live, uint64_t nwords, uint32_t run_len, PX *X = nullptr, uint8_t *pinfo = nullptr)
 {
 	constexpr bool PIPE = !std::is_same<PX, NoPipe>::value;
+	uint32_t pidx = 0;   // partition parameters read so far (they are noted in pinfo[], if the caller wants them)
 	uint32_t hand = 0;   // PIPE: which of the two exchange buffers is being filled
 	// the coefficients stay zero through the warm-up samples, which are stored as they are, and
 	// are switched on at the first residual; lanes without a predictor keep zeros
@@ -300,6 +301,11 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 			if (escape) {
 				raw_bits = br_get(r, 5);
 				k = 0;
+			}
+			if (!SKIP && pinfo) {
+				if (pidx < FA_INFO_PARAMS)
+					pinfo[pidx] = (uint8_t)(escape ? 0x80u | raw_bits : k);
+				pidx++;
 			}
 			part_end = h.po > 0 ? part_end + h.psize : bsf;
 		} while (part_end <= i && !r.err && br_pos(r) <= r.bend);
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 		pump_service(pm, r, L, tid, live, nwords);
 		// ---- subframe header (stream_decoder.c:2450-2518) ----
 		SubHdr h;
-		h.kind = 0; h.order = 0; h.wasted = 0; h.po = 0; h.plen = 4; h.pesc = 15; h.psize = 0; h.shift = 0; h.lane_wide = false; h.constant = 0;
+		h.kind = 0; h.order = 0; h.wasted = 0; h.po = 0; h.plen = 4; h.pesc = 15; h.psize = 0; h.shift = 0; h.lane_wide = false; h.constant = 0; h.prec = 0;
 		h.sbps = P.bps;
 		if ((cd.assignment == 1 && c == 1) || (cd.assignment == 2 && c == 0) || (cd.assignment == 3 && c == 1))
 			h.sbps++;
@@ -1019,6 +1025,7 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 					if (prec == 15)
 						r.err = true;  // stream_decoder.c:2622
 					prec++;
+					h.prec = prec;
 					h.shift = br_get_signed(r, 5);
 					if (h.shift < 0)
 						h.shift = 0;  // the reference's shift by a negative count is undefined; it never writes one
@@ -1056,6 +1063,26 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 		const bool any_wide = __any(predictive && h.lane_wide);
 		const bool all24 = __all(!predictive || h.sbps <= 24);
 		const bool run = live && !r.err;
+		// what the caller may want to know about the subframe besides its samples
+		uint8_t *pinfo = nullptr;
+		if (SUBM && P.subinfo && run) {
+			FaSubInfo *info = P.subinfo + (size_t)j * P.channels + c;
+			info->type = (uint8_t)h.kind;
+			info->order = (uint8_t)h.order;
+			info->wasted = (uint8_t)h.wasted;
+			info->precision = (uint8_t)h.prec;
+			info->shift = (int8_t)h.shift;
+			info->po = (uint8_t)h.po;
+			info->rice2 = h.plen == 5 ? 1 : 0;
+			info->constant = h.constant;
+			if (h.kind >= 2) {
+				for (uint32_t i = 0; i < h.order; i++) {
+					info->warm[i] = L.w[i][lane];
+					info->q[i] = h.kind == 3 ? L.q[i][lane] : 0;
+				}
+			}
+			pinfo = info->params;
+		}
 		if constexpr (PIPE) {
 			if (tid < LW) {
 				X.order[lane] = h.order;
@@ -1064,14 +1091,14 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 				X.flags[lane] = (predictive ? 1u : 0u) | (h.lane_wide ? 2u : 0u) | (h.sbps <= 24 ? 4u : 0u);
 			}
 			__syncthreads();
-			decode_samples<0, false, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, &X);
+			decode_samples<0, false, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, &X, pinfo);
 			continue;
 		}
 #define DECODE(M) \
 	do { \
-		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
-		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
-		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len); \
+		if (any_wide) decode_samples<M, true, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, (NoPipe *)nullptr, pinfo); \
+		else if (all24) decode_samples<M, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, (NoPipe *)nullptr, pinfo); \
+		else decode_samples<M, false, false>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len, (NoPipe *)nullptr, pinfo); \
 	} while (0)
 		if (MODE == DEC_SKIP) {
 			decode_samples<0, false, false, true>(r, pm, h, L, plane, LW, tid, bs_w, bsf, run, nwords, run_len);

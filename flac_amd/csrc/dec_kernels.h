@@ -6,6 +6,8 @@
 
 #include "flac_amd_internal.h"
 
+struct FaSubInfo;
+
 struct FaDecParams {
 	uint32_t channels, bps, max_blocksize, out_sample_bytes;
 	uint32_t nstreams, max_frames;
@@ -15,6 +17,20 @@ struct FaDecParams {
 	uint32_t run;            // samples between the frame decoder's service points where nothing but plain symbols lies ahead (16, 32, 64)
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
+	FaSubInfo *subinfo;      // max_frames * channels records to fill, or null
+};
+
+// One record per (frame, channel) when the caller wants them: the layout of flacamd_subframe_info (include/flac_amd.h).
+#define FA_INFO_PARAMS 256
+struct FaSubInfo {
+	uint8_t type, order, wasted, precision;
+	int8_t shift;
+	uint8_t po, rice2, pad;
+	int32_t constant;
+	uint32_t pad2[2];
+	int32_t q[32];
+	int32_t warm[32];
+	uint8_t params[FA_INFO_PARAMS];
 };
 
 struct FaStream {

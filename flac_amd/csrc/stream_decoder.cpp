@@ -7,9 +7,12 @@
 // it is decoded by one flacamd_decode_streams call, and the write callback is then fed frame after
 // frame in stream order from the decoded batch.  Callbacks run on the caller's thread.
 //
-// What the write callback's FLAC__Frame carries: the complete header and footer.  The per-subframe
-// analysis fields (predictor type, order, coefficients, residual pointers) are zero: they exist only
-// inside the device kernels.
+// What the write callback's FLAC__Frame carries: the complete header and footer, and per subframe what
+// read_subframe_ (stream_decoder.c:2450-2713) learns on the way to the samples - type, wasted bits, order,
+// warm-up samples, coefficient precision, quantization level, coefficients, Rice method, partition order, and
+// the first 256 partitions' parameters / raw bits - which the device kernels note for every subframe and the
+// batch brings back beside the samples.  The residual itself stays on the device: the residual pointers
+// (FLAC__Subframe_Fixed / _LPC.residual, FLAC__Subframe_Verbatim.data) point at zeros.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -103,8 +106,13 @@ struct FLAC__StreamDecoderPrivate {
 
 	// ---- the decoded batch being handed out ----
 	std::vector<flacamd_frame_info> *table;
+	std::vector<flacamd_subframe_info> *subinfo;   // `channels` records per row of the table
+	// what FLAC__Frame.subframes[] points at: per channel the partition parameters and raw bits of the frame in hand
+	FLAC__EntropyCodingMethod_PartitionedRiceContents rice_contents[FLAC__MAX_CHANNELS];
+	std::vector<unsigned> *rice_words;             // 2 x FLACAMD_SUBFRAME_PARAMS per channel
+	std::vector<FLAC__int32> *no_residual;         // max blocksize zeros
 	size_t cursor;
-	bool batch_active, batch_eof, batch_cut, batch_full;
+	bool batch_active, batch_eof, batch_cut, batch_full, want_subinfo;
 	size_t batch_base, batch_len;   // the batch covers in[batch_base, batch_base+batch_len)
 	uint64_t walk_pos;              // bytes of the batch already accounted for
 	bool gap_reported;
@@ -975,6 +983,15 @@ bool ensure_device(FLAC__StreamDecoder *d)
 	if (flacamd_decoder_create(ch, bps, bs, fa_stream_device(), q->batch_bytes, q->max_frames, &q->dev) != FLACAMD_OK)
 		return device_fail(d, "cannot create the device decoder");
 	(void)flacamd_decoder_set_frame_number_scale(q->dev, scale);
+	// FLAC_AMD_DEC_SUBFRAMES=0: FLAC__Frame.subframes[] stay zero (saves the records' way back: 528 bytes per subframe)
+	{
+		const char *env = getenv("FLAC_AMD_DEC_SUBFRAMES");
+		if (!(env && !strcmp(env, "0")) && flacamd_decoder_enable_subframe_info(q->dev, 1) != FLACAMD_OK)
+			return device_fail(d, "cannot create the device decoder");
+		q->want_subinfo = !(env && !strcmp(env, "0"));
+		q->rice_words->assign((size_t)2 * FLACAMD_SUBFRAME_PARAMS * FLAC__MAX_CHANNELS, 0u);
+		q->no_residual->assign((size_t)bs + 1, 0);
+	}
 	const size_t out_bytes = (size_t)q->out_cap_wide * ch * sizeof(FLAC__int32);
 	if (hipMalloc((void **)&q->d_in, q->batch_bytes + 16) != hipSuccess || hipMalloc((void **)&q->d_out, out_bytes) != hipSuccess ||
 	    hipHostMalloc((void **)&q->h_out, out_bytes, hipHostMallocDefault) != hipSuccess) {
@@ -1096,6 +1113,12 @@ bool start_batch(FLAC__StreamDecoder *d)
 		return device_fail(d, "decode failed");
 	q->table->resize(n);
 	q->batch_cut = cut != 0;
+	q->subinfo->clear();
+	if (q->want_subinfo && n) {
+		q->subinfo->resize((size_t)n * q->dev_channels);
+		if (flacamd_decoder_subframe_info(q->dev, 0, n, q->subinfo->data()) != FLACAMD_OK)
+			return device_fail(d, "decode failed");
+	}
 	// bring back the span of samples the good frames cover
 	uint64_t used = 0;
 	if (n) {
@@ -1115,6 +1138,65 @@ bool start_batch(FLAC__StreamDecoder *d)
 		return false;
 	}
 	return true;
+}
+
+// FLAC__Frame.subframes[] of the frame in hand from the records the device kept (what read_subframe_constant_ /
+// _fixed_ / _lpc_ / _verbatim_, stream_decoder.c:2520-2713, leave in the frame)
+void fill_subframes(FLAC__StreamDecoderPrivate *q, const flacamd_subframe_info *rec, unsigned channels)
+{
+	for (unsigned c = 0; c < channels; c++) {
+		const flacamd_subframe_info &r = rec[c];
+		FLAC__Subframe &sf = q->frame.subframes[c];
+		sf.wasted_bits = r.wasted_bits;
+		FLAC__EntropyCodingMethod *ecm = 0;
+		switch (r.type) {
+		case 0:
+			sf.type = FLAC__SUBFRAME_TYPE_CONSTANT;
+			sf.data.constant.value = r.constant;
+			break;
+		case 1:
+			sf.type = FLAC__SUBFRAME_TYPE_VERBATIM;
+			sf.data.verbatim.data = q->no_residual->data();
+			break;
+		case 2:
+			sf.type = FLAC__SUBFRAME_TYPE_FIXED;
+			sf.data.fixed.order = r.order;
+			for (unsigned i = 0; i < r.order && i < FLAC__MAX_FIXED_ORDER; i++)
+				sf.data.fixed.warmup[i] = r.warmup[i];
+			sf.data.fixed.residual = q->no_residual->data();
+			ecm = &sf.data.fixed.entropy_coding_method;
+			break;
+		default:
+			sf.type = FLAC__SUBFRAME_TYPE_LPC;
+			sf.data.lpc.order = r.order;
+			sf.data.lpc.qlp_coeff_precision = r.precision;
+			sf.data.lpc.quantization_level = r.shift;
+			for (unsigned i = 0; i < r.order && i < FLAC__MAX_LPC_ORDER; i++) {
+				sf.data.lpc.qlp_coeff[i] = r.qlp_coeff[i];
+				sf.data.lpc.warmup[i] = r.warmup[i];
+			}
+			sf.data.lpc.residual = q->no_residual->data();
+			ecm = &sf.data.lpc.entropy_coding_method;
+			break;
+		}
+		if (ecm) {
+			ecm->type = r.rice2 ? FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 : FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE;
+			ecm->data.partitioned_rice.order = r.partition_order;
+			unsigned *par = q->rice_words->data() + (size_t)c * 2 * FLACAMD_SUBFRAME_PARAMS, *raw = par + FLACAMD_SUBFRAME_PARAMS;
+			const unsigned esc = r.rice2 ? 31u : 15u;
+			for (unsigned i = 0; i < FLACAMD_SUBFRAME_PARAMS; i++) {
+				const bool have = r.partition_order >= 31 ? false : i < (1u << r.partition_order);
+				const bool escaped = have && (r.params[i] & 0x80u);
+				par[i] = !have ? 0u : escaped ? esc : r.params[i];
+				raw[i] = escaped ? (r.params[i] & 31u) : 0u;
+			}
+			FLAC__EntropyCodingMethod_PartitionedRiceContents &ct = q->rice_contents[c];
+			ct.parameters = par;
+			ct.raw_bits = raw;
+			ct.capacity_by_order = 8;   // what the arrays hold: 2^8 partitions (a frame cut finer than that shows its first 256)
+			ecm->data.partitioned_rice.contents = &ct;
+		}
+	}
 }
 
 // write_audio_frame_to_client_ (stream_decoder.c:2913)
@@ -1275,6 +1357,8 @@ bool next_frame(FLAC__StreamDecoder *d, bool *got_a_frame, bool do_full_decode)
 		} else
 			fh.number.sample_number = (FLAC__uint64)h.blocksize * h.number;
 		q->frame.footer.crc = (FLAC__uint16)(((unsigned)src[f.end_byte - f.pos - 2] << 8) | src[f.end_byte - f.pos - 1]);
+		if (q->subinfo->size() >= (q->cursor + 1) * (size_t)h.channels)
+			fill_subframes(q, &(*q->subinfo)[q->cursor * (size_t)h.channels], h.channels);
 		FLAC__int32 *inter = q->h_out + (size_t)(f.sample - s0) * h.channels;
 		if (f.status == 3) {
 			// :2105-2113
@@ -1624,11 +1708,18 @@ FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
 	if (d->private_) {
 		d->private_->filter_ids = new (std::nothrow) std::vector<FLAC__byte>();
 		d->private_->table = new (std::nothrow) std::vector<flacamd_frame_info>();
+		d->private_->subinfo = new (std::nothrow) std::vector<flacamd_subframe_info>();
+		d->private_->rice_words = new (std::nothrow) std::vector<unsigned>();
+		d->private_->no_residual = new (std::nothrow) std::vector<FLAC__int32>();
 	}
-	if (!d->protected_ || !d->private_ || !d->private_->filter_ids || !d->private_->table) {
+	if (!d->protected_ || !d->private_ || !d->private_->filter_ids || !d->private_->table || !d->private_->subinfo || !d->private_->rice_words ||
+	    !d->private_->no_residual) {
 		if (d->private_) {
 			delete d->private_->filter_ids;
 			delete d->private_->table;
+			delete d->private_->subinfo;
+			delete d->private_->rice_words;
+			delete d->private_->no_residual;
 		}
 		free(d->private_);
 		free(d->protected_);
@@ -1651,6 +1742,9 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 	free(q->seek_table.data.seek_table.points);
 	delete q->filter_ids;
 	delete q->table;
+	delete q->subinfo;
+	delete q->rice_words;
+	delete q->no_residual;
 	free(d->private_);
 	free(d->protected_);
 	free(d);

@@ -204,6 +204,32 @@ typedef struct {
 	uint32_t reserved;   /* with status 2: 1 when the parse stopped at a reserved subframe type or
 	                        residual coding method (the reference's UNPARSEABLE_STREAM), else 0 */
 } flacamd_frame_info;
+/* What read_subframe_ (stream_decoder.c:2450-2713) learns about one subframe besides its samples: what the
+ * reference's write callback finds in FLAC__Frame.subframes[] (consumed by `flac --analyze`, src/flac/analyze.c:63-144),
+ * except for the residual itself, which stays on the device. */
+#define FLACAMD_SUBFRAME_PARAMS 256
+typedef struct {
+	uint8_t type;        /* 0 constant, 1 verbatim, 2 fixed, 3 LPC */
+	uint8_t order;
+	uint8_t wasted_bits;
+	uint8_t precision;   /* LPC: bits per coefficient */
+	int8_t shift;        /* LPC: quantization level */
+	uint8_t partition_order;
+	uint8_t rice2;       /* 1: five-bit Rice parameters (FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2) */
+	uint8_t pad;
+	int32_t constant;    /* type 0: the value (before the wasted bits are shifted back in) */
+	uint32_t pad2[2];
+	int32_t qlp_coeff[32];
+	int32_t warmup[32];
+	/* per partition, the first FLACAMD_SUBFRAME_PARAMS of them: the Rice parameter, or 0x80 | raw bits of an escaped partition */
+	uint8_t params[FLACAMD_SUBFRAME_PARAMS];
+} flacamd_subframe_info;
+/* Off by default.  on: the decoder keeps one record per (frame, channel) on the device, filled by every decode from then on. */
+int flacamd_decoder_enable_subframe_info(flacamd_decoder *d, int on);
+/* Blocks until the decode finished, then copies the records of frames [first_frame, first_frame + nframes) of the table
+ * of flacamd_decoder_frames: `channels` consecutive records per frame.  Records of frames whose status is not 1 or 3 are
+ * undefined. */
+int flacamd_decoder_subframe_info(flacamd_decoder *d, uint32_t first_frame, uint32_t nframes, flacamd_subframe_info *out);
 /* Blocks until the decode finished, then copies up to `capacity` rows.  *truncated is set when
  * the input held more frame headers than the decoder's max_frames or than `capacity`. */
 int flacamd_decoder_frames(flacamd_decoder *d, flacamd_frame_info *out, uint32_t capacity,

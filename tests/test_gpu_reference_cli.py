@@ -81,6 +81,56 @@ def test_encode_decode_test_match_the_reference_tool(tools, tmp_path, bps, chann
     assert channels > 2 or len(aw.read_bytes()) == 44 + (s1 - s0) * channels * (bps // 8)
 
 
+def _analysis_material(kind):
+    """Samples that make the encoder use every subframe type, wasted bits, escaped and many partitions."""
+    from flac_amd.synth import synth_pcm
+    rng = np.random.default_rng(9)
+    if kind == "music16":
+        return synth_pcm(seconds=6, sample_rate=44100, channels=2, bits_per_sample=16, seed=3), 16, 44100
+    if kind == "music24_wasted":
+        pcm = synth_pcm(seconds=3, sample_rate=96000, channels=2, bits_per_sample=24, seed=4)
+        return (pcm >> 5) << 5, 24, 96000   # five wasted bits in every subframe
+    if kind == "mixed16":
+        n = 44100 * 3
+        pcm = synth_pcm(wide_samples=n, sample_rate=44100, channels=2, bits_per_sample=16, seed=6)
+        pcm[20000:40000] = 0                                   # silence: constant subframes
+        pcm[50000:70000, 0] = 1234                             # a constant that is not zero, one channel
+        pcm[80000:100000] = rng.integers(-32768, 32768, size=(20000, 2))   # full-scale noise: verbatim subframes
+        return pcm, 16, 44100
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,opts", [
+    ("music16", ["-8"]),
+    ("music16", ["-2"]),                       # fixed predictors only
+    ("music16", ["-8", "-r", "8,8"]),          # 256 partitions per subframe
+    ("music16", ["-5", "-b", "1152"]),
+    ("music24_wasted", ["-8"]),
+    ("mixed16", ["-8"]),
+], ids=["l8", "l2_fixed", "l8_po8", "l5_bs1152", "l8_24_wasted", "l8_mixed"])
+def test_analysis_output_matches_the_reference_tool(tools, tmp_path, kind, opts):
+    """`flac -a` prints what the write callback's FLAC__Frame.subframes[] say (src/flac/analyze.c:63-144): subframe
+    type, wasted bits, order, warm-up, coefficient precision, quantization level, coefficients, Rice method, partition
+    order and every partition's parameter, besides each frame's offset and size.  Same text from both tools."""
+    on_amd, ref = tools
+    pcm, bps, rate = _analysis_material(kind)
+    wav = tmp_path / "in.wav"
+    wav.write_bytes(wav_bytes(pcm, bps, rate))
+    f = tmp_path / "in.flac"
+    assert run(ref, "-f", "-o", str(f), *opts, str(wav)).returncode == 0
+    a, b = tmp_path / "a.ana", tmp_path / "b.ana"
+    r = run(on_amd, "-a", "-f", "-o", str(a), str(f))
+    assert r.returncode == 0, r.stderr
+    assert run(ref, "-a", "-f", "-o", str(b), str(f)).returncode == 0
+    ta, tb = a.read_text(), b.read_text()
+    assert "type=LPC" in tb or "type=FIXED" in tb
+    if kind == "mixed16":
+        assert "type=CONSTANT" in tb and "type=VERBATIM" in tb
+    if kind == "music24_wasted":
+        assert "wasted_bits=5" in tb
+    assert ta == tb, "first difference at line %d" % next(i for i, (x, y) in enumerate(zip(ta.splitlines() + [""], tb.splitlines() + [""])) if x != y)
+
+
 def test_damaged_file_fails_test_mode(tools, tmp_path):
     from flac_amd.synth import synth_pcm
     on_amd, _ref = tools
