@@ -31,6 +31,7 @@ struct flacamd_decoder {
 	uint32_t *ncand;                // [0] count, [1] overflow flag
 	int32_t *tmp;
 	uint64_t *sub_start;            // bit position at which each (frame, channel)'s subframe starts
+	uint32_t pair;                  // split form, stereo: a workgroup takes both channels of lw frames and writes final PCM (DEC_PAIR)
 	uint32_t split, skip_lw;        // the split form (walk, then every subframe at once) is used, not a launch per channel; frames per wave of its walk
 	unsigned long long *result;     // good frames, wide samples, bad candidates
 	int profiling, have_times;
@@ -162,6 +163,22 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 			const uint32_t v = (uint32_t)atoi(env);
 			if (v >= 1 && v <= (d->split ? 16u : 32u) && (v & (v - 1)) == 0)
 				lw = v;
+		}
+		// Stereo in the split form, the CRC pass running ahead: both channels of a frame in one workgroup (half as many
+		// frames per group, the same columns per wave), which then writes final PCM itself.  FLAC_AMD_DEC_PAIR=0: planes for all.
+		{
+			const char *env = getenv("FLAC_AMD_DEC_PAIR"), *side = getenv("FLAC_AMD_DEC_SIDE");
+			const bool off = (env && !strcmp(env, "0")) || (side && !strcmp(side, "0"));
+			// (the pair kernel is 25-60 us slower than the one-channel one whatever the batch - a wave's lanes are of two
+			// channels, whose partitions start at different samples - and saves the output kernel's pass over the planes,
+			// which grows with the batch: 4 096 frames 0.714 -> 0.734 ms, 6 460 frames 0.859 -> 0.814)
+			uint32_t least = 5000;
+			if (env && atoi(env) > 1)
+				least = (uint32_t)atoi(env);   // FLAC_AMD_DEC_PAIR=n: from n frames up
+			if (d->split && !off && lw >= 2 && max_frames >= least && fa_dec_pair_fits(channels, max_frames, lw / 2)) {
+				d->pair = 1;
+				lw /= 2;
+			}
 		}
 		d->lw = lw;
 		// the walk of the split form: a lane per frame again, thin enough for the input pump to keep every lane fed
@@ -296,8 +313,12 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 		HIP_TRY(hipEventRecord(d->ev_join, d->side));
 	}
 	STAGE_MARK();
-	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->sub_start, d->split != 0, st);
-	if (d->side)
+	// (the pair form needs the other stream's work - output cleared, CRC verdicts - before its second launch; otherwise
+	// the join comes after the frame decoder)
+	const bool pair = d->pair && d->side && (out_sample_bytes == 2 || out_sample_bytes == 4);
+	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->sub_start, d->split != 0, pair, d->crc_ahead,
+	                     pair ? d->ev_join : nullptr, pcm_out_dev, st);
+	if (d->side && !pair)
 		HIP_TRY(hipStreamWaitEvent(st, d->ev_join, 0));
 	STAGE_MARK();
 	fa_dec_launch_crc(P, flac_dev, d->cands, d->ncand, d->streams, d->crc_ahead, false, st);

@@ -148,7 +148,9 @@ struct __attribute__((aligned(RINGW * 4))) DecLds {
 	uint32_t ring[MAXLW][RINGW];             // input words per lane
 	int32_t q[FA_MAX_ORDER][MAXLW];          // predictor coefficients per lane
 	int32_t w[FA_MAX_ORDER][MAXLW];          // warm-up samples per lane
-	int32_t out[run * MAXLW + 1];            // a run of decoded samples, [sample][lane]; the last word: for the lanes without a frame
+	// a run of decoded samples, [sample][lane]; the last word: for the lanes without a frame.  (The two-wave forms use a
+	// row stride of MAXLW + 1 words: their way out reads a column per lane.)
+	int32_t out[run * (MAXLW + 1) + 1];
 };
 typedef __attribute__((address_space(3))) const uint32_t LdsWord;
 
@@ -161,9 +163,12 @@ typedef __attribute__((address_space(3))) const uint32_t LdsWord;
 template <int MAXLW, int RUN>
 struct PipeLds {
 	int32_t res[2][RUN * MAXLW];            // [sample][lane]
-	int32_t dummy[DEC_BLOCK * MAXLW];       // where the lanes without a frame write
+	int32_t dummy[DEC_BLOCK * (MAXLW + 1)]; // where the lanes without a frame write
 	uint32_t kf[2][MAXLW];
 	uint32_t cnt[2];
+	// DEC_PAIR, per frame of the workgroup: 1 = its samples go straight to the output (at wide sample fobase), else to the planes
+	uint32_t fkind[MAXLW], fassign[MAXLW], fbs[MAXLW];
+	uint64_t fobase[MAXLW];
 	uint32_t order[MAXLW];                  // predictor order; 0 where there is no predictor
 	uint32_t wasted[MAXLW];
 	int32_t shift[MAXLW];
@@ -570,6 +575,81 @@ __device__ __forceinline__ void decode_samples(BitRd &r, Pump &pm, const SubHdr 
 	}
 }
 
+// Where the restoring wave's samples go.
+#define PAIR_FRAMES 8   // frames per workgroup of DEC_PAIR at most (half the columns)
+struct PipeOut {
+	int32_t *plane;     // DEC_PIPE: the channel's plane of the group; DEC_PAIR: channel 0's
+	int32_t *plane1;    // DEC_PAIR: channel 1's plane
+	uint32_t sb;        // DEC_PAIR: bytes per sample of the caller's interleaved PCM (2 or 4)
+	// DEC_PAIR, per frame of the workgroup, the same in every lane (scalar registers): where its first stereo pair goes
+	// (null: to the planes), its length, its channel assignment and the wasted bits of its two subframes
+	uint8_t *dst[PAIR_FRAMES];
+	uint32_t bs[PAIR_FRAMES], assign[PAIR_FRAMES], wasted0[PAIR_FRAMES], wasted1[PAIR_FRAMES];
+};
+
+// A run of n samples from L.out ([sample][column], row stride MAXLW + 1, as restored: the wasted bits are shifted back in
+// here, stream_decoder.c:2511-2515) on its way out.  DEC_PIPE: to the channel's plane, along memory order.  DEC_PAIR: the
+// columns are FPW frames' first channel and then the same frames' second channel, so both samples of a stereo frame are at
+// hand: the decorrelation is undone (stream_decoder.c:2067-2102) and the pair goes straight to its place in the caller's
+// interleaved PCM, a lane per sample, 256 contiguous bytes per frame and run - unless the frame's CRC-16 has not been seen
+// to be right, in which case it goes to the planes like everything did before and waits for k_dec_output.
+template <bool PAIR, typename LDS, typename PX>
+__device__ __forceinline__ void pipe_flush(LDS &L, PX &X, const PipeOut &O, uint32_t LW, uint32_t tid, uint32_t i0, uint32_t n)
+{
+	constexpr uint32_t ostride = LDS::maxlw + 1;
+	if constexpr (!PAIR) {
+		const uint32_t col = tid & (LDS::maxlw - 1);
+		static_assert(DEC_LANES % LDS::maxlw == 0, "a thread stays with one column");
+		if (col < LW) {
+			const uint32_t col_wasted = X.wasted[col];
+			const uint32_t lim = n * LDS::maxlw;
+			for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
+				int32_t v[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					const uint32_t e = e0 + u * DEC_LANES;
+					v[u] = e < lim ? L.out[(e / LDS::maxlw) * ostride + col] : 0;
+				}
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					const uint32_t e = e0 + u * DEC_LANES;
+					if (e < lim)
+						O.plane[(size_t)(i0 + (e / LDS::maxlw)) * LW + col] = (int32_t)((uint32_t)v[u] << col_wasted);
+				}
+			}
+		}
+	} else {
+		const uint32_t FPW = LW >> 1;
+		const uint32_t i = i0 + tid;
+#pragma unroll
+		for (uint32_t k = 0; k < PAIR_FRAMES; k++) {
+			if (k < FPW && tid < n && i < O.bs[k]) {
+				int32_t a = (int32_t)((uint32_t)L.out[tid * ostride + k] << O.wasted0[k]);
+				int32_t b = (int32_t)((uint32_t)L.out[tid * ostride + k + FPW] << O.wasted1[k]);
+				if (O.dst[k]) {
+					if (O.assign[k] == 1)
+						b = a - b;
+					else if (O.assign[k] == 2)
+						a = a + b;
+					else if (O.assign[k] == 3) {
+						int32_t mid = (int32_t)((uint32_t)a << 1);
+						mid |= (b & 1);
+						a = (mid + b) >> 1;
+						b = (mid - b) >> 1;
+					}
+					if (O.sb == 2)
+						((uint32_t *)O.dst[k])[i] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+					else
+						((int2 *)O.dst[k])[i] = make_int2(a, b);
+				} else {
+					O.plane[(size_t)i * FPW + k] = a;
+					O.plane1[(size_t)i * FPW + k] = b;
+				}
+			}
+		}
+	}
+}
+
 // Rice symbols that were handed over as they lie in the stream: thread t looks after the words of lane t mod 16,
 // four samples at a time (bitreader.c:775: zeros up to the stop bit, then the parameter's worth of low bits; zigzag)
 template <typename LDS, typename PX>
@@ -610,20 +690,17 @@ __device__ __forceinline__ void pipe_cut_symbols(PX &X, uint32_t hand, uint32_t 
 // The four sit in the four banks of a row of sixteen lanes (lane = 16 r + 4 t + i for subframe 4 r + i), so that
 // "the next thread" is a shift by four lanes and "not the first" is a bank mask.  The samples stay as they are in LDS
 // ([sample][lane], the instance's stride); the wasted bits are shifted back in on the way out.
-template <int T, bool MUL24, typename LDS, typename PX>
-__device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t need)
+template <int T, bool MUL24, bool PAIR, typename LDS, typename PX>
+__device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, const PipeOut &O, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t need)
 {
 	static_assert(LDS::maxlw == 16 && DEC_LANES == 64, "four threads per subframe, sixteen subframes");
-	constexpr uint32_t xstride = LDS::maxlw;
+	constexpr uint32_t xstride = LDS::maxlw, ostride = LDS::maxlw + 1;
 	const uint32_t f = ((tid >> 4) << 2) | (tid & 3u), t = (tid >> 2) & 3u;
 	const bool have = f < LW;
 	const uint32_t fl = have ? f : 0;
 	const bool predictive = have && (X.flags[fl] & 1u);
 	const uint32_t order = predictive ? X.order[fl] : 0;
 	const int shift = have ? X.shift[fl] : 0;
-	// (for the way out, where thread t looks after column t mod 16)
-	const uint32_t col = tid & (xstride - 1);
-	const uint32_t col_wasted = col < LW ? X.wasted[col] : 0;
 	int32_t q[T], h[T];
 #pragma unroll
 	for (int u = 0; u < T; u++) {
@@ -663,7 +740,7 @@ __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, int32_t *plane, 
 #pragma nounroll
 		for (uint32_t b0 = 0; b0 < n; b0 += DEC_BLOCK) {
 			const int32_t *bsrc = src + (have ? b0 * xstride : 0u);
-			int32_t *bslot = have ? &L.out[b0 * xstride + f] : &X.dummy[0];
+			int32_t *bslot = have ? &L.out[b0 * ostride + f] : &X.dummy[0];
 			// (all of the block's values first: a load between the stores would be waited for sample by sample)
 			int32_t rv[DEC_BLOCK];
 #pragma unroll
@@ -678,29 +755,15 @@ __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, int32_t *plane, 
 						for (int u = 0; u < T; u++)
 							q[u] = T * t + u < order ? L.q[T * t + u][fl] : 0;
 					}
-					bslot[s * xstride] = step(rv[s]);
+					bslot[s * ostride] = step(rv[s]);
 				}
 			} else {
 #pragma unroll
 				for (uint32_t s = 0; s < DEC_BLOCK; s++)
-					bslot[s * xstride] = step(rv[s]);
+					bslot[s * ostride] = step(rv[s]);
 			}
 		}
-		if (col < LW) {
-			const uint32_t lim = n * xstride;
-			for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
-				int32_t v[8];
-#pragma unroll
-				for (uint32_t u = 0; u < 8; u++)
-					v[u] = e0 + u * DEC_LANES < lim ? L.out[e0 + u * DEC_LANES] : 0;
-#pragma unroll
-				for (uint32_t u = 0; u < 8; u++) {
-					const uint32_t e = e0 + u * DEC_LANES;
-					if (e < lim)
-						plane[(size_t)(i0 + (e / xstride)) * LW + col] = (int32_t)((uint32_t)v[u] << col_wasted);
-				}
-			}
-		}
+		pipe_flush<PAIR>(L, X, O, LW, tid, i0, n);
 		i0 += n;
 		hand ^= 1u;
 	}
@@ -711,9 +774,9 @@ __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, int32_t *plane, 
 // (stream_decoder.c:2511-2515), the samples collected a run at a time and written to the planes along memory order.
 // A lane's predictor is switched on at the sample that follows its warm-up; only the first blocks of a subframe
 // (up to the largest order in the wave) have to look for that sample.
-template <int M, bool WIDE, bool MUL24, typename LDS, typename PX>
-__device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t order, bool predictive,
-                                            int shift, bool lane_wide, uint32_t wasted, uint32_t need)
+template <int M, bool WIDE, bool MUL24, bool PAIR, typename LDS, typename PX>
+__device__ __forceinline__ void restore_run(LDS &L, PX &X, const PipeOut &O, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t order, bool predictive,
+                                            int shift, bool lane_wide, uint32_t need)
 {
 	int32_t q[M > 0 ? M : 1], hist[M > 0 ? M : 1];
 #pragma unroll
@@ -722,9 +785,7 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 		hist[j] = 0;
 	}
 	const uint32_t lane = tid < (uint32_t)LDS::maxlw ? tid : 0;
-	constexpr uint32_t xstride = LDS::maxlw;   // of the exchange buffers
-	const uint32_t rstride = tid < LW ? LW : 0u;
-	int32_t *const slot = &L.out[tid < LW ? tid : (uint32_t)(LDS::run * LDS::maxlw)];
+	constexpr uint32_t xstride = LDS::maxlw, ostride = LDS::maxlw + 1;   // of the exchange buffers, of the samples on their way out
 	auto step = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
 		int32_t v = res;
 		if (M > 0) {
@@ -773,7 +834,7 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 #pragma nounroll
 		for (uint32_t b0 = 0; b0 < n; b0 += DEC_BLOCK) {
 			const int32_t *bsrc = src + (tid < LW ? b0 * xstride : 0u);
-			int32_t *bslot = slot + b0 * rstride;
+			int32_t *bslot = tid < LW ? &L.out[b0 * ostride + tid] : &X.dummy[0];
 			// (all of the block's values first: a load between the stores would be waited for sample by sample)
 			int32_t rv[DEC_BLOCK];
 #pragma unroll
@@ -788,17 +849,15 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 						for (int j = 0; j < M; j++)
 							q[j] = (uint32_t)j < order ? L.q[j][lane] : 0;
 					}
-					bslot[s * rstride] = (int32_t)((uint32_t)step(rv[s]) << wasted);
+					bslot[s * ostride] = step(rv[s]);
 				}
 			} else {
 #pragma unroll
 				for (uint32_t s = 0; s < DEC_BLOCK; s++)
-					bslot[s * rstride] = (int32_t)((uint32_t)step(rv[s]) << wasted);
+					bslot[s * ostride] = step(rv[s]);
 			}
 		}
-		const uint32_t nblk = n * LW;
-		for (uint32_t e = tid; e < nblk; e += DEC_LANES)
-			plane[(size_t)i0 * LW + e] = L.out[e];
+		pipe_flush<PAIR>(L, X, O, LW, tid, i0, n);
 		i0 += n;
 		hand ^= 1u;
 	}
@@ -826,36 +885,44 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, int32_t *plane, uint3
 // DEC_PIPE is DEC_SUB with two waves to a workgroup: the first reads the symbols, the second turns them into samples and
 // writes them out, a run behind.  Reading is the longer half, so the chain per subframe shrinks to that; the chip has
 // to have room for twice the waves, which is what the split form is used for anyway.
+// DEC_PAIR is DEC_PIPE for stereo with both channels of a frame in one workgroup: the columns are LW / 2 frames' first
+// subframes and then the same frames' second ones, so the restoring wave has both samples of every stereo pair and writes
+// final interleaved PCM itself (pipe_flush): no planes, no output kernel for those frames.
 #define DEC_SKIP 1
 #define DEC_SUB 2
 #define DEC_PIPE 3
+#define DEC_PAIR 4
 #define DEC_NO_START 0xffffffffffffffffull
 
 // DEEP: four chunks per ring instead of two (and room for runs of four blocks): half as much LDS again per wave, so only
 // for launches whose waves all find room on the chip even so (the launcher decides)
 template <int MODE, int MAXLW, bool DEEP>
-__global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
+// LW: columns (subframes) per wave.  ahead, pcm_out: DEC_PAIR only (what the CRC pass that ran ahead found; the caller's PCM).
+__global__ __launch_bounds__((MODE == DEC_PIPE || MODE == DEC_PAIR) ? 2 * DEC_LANES : DEC_LANES, 2) void k_dec_frames(FaDecParams P, const uint32_t *flac_words, const FaStream *streams,
                                                           FaFrameCand *cands, const uint32_t *ncand_ptr, int32_t *tmp, uint32_t LW, uint64_t *sub_start,
-                                                          uint32_t chain)
+                                                          uint32_t chain, const uint64_t *ahead, void *pcm_out)
 {
 	__shared__ DecLds<MAXLW, (DEEP ? RING_WORDS_BIG : RING_WORDS_MIN)> L;
-	constexpr bool SUBM = MODE == DEC_SUB || MODE == DEC_PIPE;   // one subframe per lane, from a known start
-	constexpr bool PIPE = MODE == DEC_PIPE;
+	constexpr bool PAIR = MODE == DEC_PAIR;
+	constexpr bool PIPE = MODE == DEC_PIPE || PAIR;
+	constexpr bool SUBM = MODE == DEC_SUB || PIPE;   // one subframe per lane, from a known start
 	using Xchg = PipeLds<MAXLW, (DEEP ? DEC_RUN_BIG : DEC_RUN_MIN)>;
 	__shared__ typename std::conditional<PIPE, Xchg, NoPipe>::type X;
 	const uint32_t run_len = umin_u32(P.run, (uint32_t)(DEEP ? DEC_RUN_BIG : DEC_RUN_MIN));
 	const uint32_t tid = threadIdx.x & (DEC_LANES - 1);
 	const uint32_t ncand = ncand_ptr[0];
-	const bool chained = SUBM && chain != DEC_NO_CHAIN;
-	const uint32_t grp = (SUBM && !chained) ? blockIdx.x / P.channels : blockIdx.x;
-	const uint32_t only_c = SUBM ? (chained ? chain : blockIdx.x % P.channels) : 0;
-	if (grp * LW >= ncand)
+	const bool chained = SUBM && !PAIR && chain != DEC_NO_CHAIN;
+	// frames per workgroup (a power of two), which frame and which channel a column is
+	const uint32_t FPW = PAIR ? LW >> 1 : LW;
+	const uint32_t grp = (SUBM && !PAIR && !chained) ? blockIdx.x / P.channels : blockIdx.x;
+	const uint32_t only_c = PAIR ? (tid < LW && tid >= FPW ? 1u : 0u) : SUBM ? (chained ? chain : blockIdx.x % P.channels) : 0;
+	if (grp * FPW >= ncand)
 		return;
-	const uint32_t j = grp * LW + tid;
+	const uint32_t j = grp * FPW + (PAIR ? (tid & (FPW - 1)) : tid);
 	const bool have_frame = tid < LW && j < ncand;
 	bool live = have_frame;
 	const uint32_t lane = tid < (uint32_t)MAXLW ? tid : 0;
-	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * LW;
+	int32_t *frame_tmp = tmp + (size_t)grp * P.channels * P.max_blocksize * FPW;
 	if constexpr (PIPE) {
 		if (threadIdx.x >= DEC_LANES) {
 			// ---- the restoring wave ----
@@ -865,11 +932,59 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 				const uint32_t t = __shfl_xor(bs_w, o, 64);
 				bs_w = t > bs_w ? t : bs_w;
 			}
-			int32_t *plane = frame_tmp + (size_t)only_c * P.max_blocksize * LW;
+			PipeOut O;
+			O.plane = frame_tmp + (PAIR ? 0 : (size_t)only_c * P.max_blocksize * LW);
+			O.plane1 = frame_tmp + (size_t)P.max_blocksize * FPW;
+			O.sb = P.out_sample_bytes;
+			if constexpr (PAIR) {
+				// Where each frame's samples go.  Straight to the output if the CRC pass that ran ahead found the CRC-16 right
+				// at the end it guessed (the frame is what it seems then, bar one chance in 65 536) and the frame has a place
+				// there (what k_dec_output checks); else to the planes.
+				if (tid < FPW) {
+					const uint32_t jj = grp * FPW + tid;
+					uint32_t kind = 0, assign = 0, bs = 0;
+					uint64_t obase = 0;
+					if (jj < ncand) {
+						const FaFrameCand *cf = cands + jj;
+						bs = cf->blocksize;
+						assign = cf->assignment;
+						const uint64_t smp = cf->sample;
+						const FaStream st = streams[cf->stream];
+						const uint64_t first = st.first_sample == ~0ull ? cands[0].sample : st.first_sample;
+						const bool verified = ahead && (ahead[jj] >> 63);
+						if (verified && smp >= first) {
+							const uint64_t rel = smp - first;
+							if (!(st.total_samples && rel + bs > st.total_samples) && st.sample_offset + rel + bs <= P.out_capacity_wide) {
+								kind = 1;
+								obase = st.sample_offset + rel;
+							}
+						}
+					}
+					X.fkind[tid] = kind;
+					X.fassign[tid] = assign;
+					X.fbs[tid] = bs;
+					X.fobase[tid] = obase;
+				}
+			}
 			__syncthreads();   // the subframe headers are in
+			if constexpr (PAIR) {
+#pragma unroll
+				for (uint32_t k = 0; k < PAIR_FRAMES; k++) {
+					const bool in = k < FPW;
+					const uint32_t kind = in ? X.fkind[k] : 0;
+					const uint64_t at = in ? X.fobase[k] : 0;
+					const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)at), hi = __builtin_amdgcn_readfirstlane((uint32_t)(at >> 32));
+					O.dst[k] = __builtin_amdgcn_readfirstlane(kind) == 1
+						? (uint8_t *)pcm_out + (((uint64_t)hi << 32) | lo) * (2u * P.out_sample_bytes) : nullptr;
+					O.bs[k] = __builtin_amdgcn_readfirstlane(in ? X.fbs[k] : 0);
+					O.assign[k] = __builtin_amdgcn_readfirstlane(in ? X.fassign[k] : 0);
+					O.wasted0[k] = __builtin_amdgcn_readfirstlane(in ? X.wasted[k] : 0);
+					O.wasted1[k] = __builtin_amdgcn_readfirstlane(in ? X.wasted[k + FPW] : 0);
+				}
+			}
 			const uint32_t flags = tid < LW ? X.flags[lane] : 0;
 			const bool predictive = flags & 1u, lane_wide = flags & 2u;
-			const uint32_t order = predictive ? X.order[lane] : 0, wasted = tid < LW ? X.wasted[lane] : 0;
+			const uint32_t order = predictive ? X.order[lane] : 0;
 			const int shift = tid < LW ? X.shift[lane] : 0;
 			uint32_t need = order;
 #pragma unroll
@@ -879,11 +994,11 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 			}
 			const bool any_wide = __any(predictive && lane_wide);
 			const bool all24 = __all(!predictive || (flags & 4u));
-#define RESTORE(M, WIDE) restore_run<M, WIDE, false>(L, X, plane, LW, tid, bs_w, order, predictive, shift, lane_wide, wasted, need)
+#define RESTORE(M, WIDE) restore_run<M, WIDE, false, PAIR>(L, X, O, LW, tid, bs_w, order, predictive, shift, lane_wide, need)
 #define RESTORE_QUAD(T) \
 	do { \
-		if (all24) restore_run_quad<T, true>(L, X, plane, LW, tid, bs_w, need); \
-		else restore_run_quad<T, false>(L, X, plane, LW, tid, bs_w, need); \
+		if (all24) restore_run_quad<T, true, PAIR>(L, X, O, LW, tid, bs_w, need); \
+		else restore_run_quad<T, false, PAIR>(L, X, O, LW, tid, bs_w, need); \
 	} while (0)
 			if (need == 0) RESTORE(0, false);
 			else if (!any_wide) {
@@ -972,10 +1087,11 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 	}
 	bool reserved_code = false;  // the parse stopped at a reserved subframe type or residual coding method
 
-	const uint32_t c_first = SUBM ? only_c : 0;
-	const uint32_t c_end = SUBM ? only_c + 1 : P.channels - 1;
-	for (uint32_t c = c_first; c < c_end; c++) {
-		int32_t *plane = frame_tmp + (size_t)c * P.max_blocksize * LW;
+	// the walk passes every channel but the last; the other modes take one subframe per lane (in DEC_PAIR: of either channel)
+	const uint32_t npass = SUBM ? 1u : P.channels - 1;
+	for (uint32_t pass = 0; pass < npass; pass++) {
+		const uint32_t c = SUBM ? only_c : pass;
+		int32_t *plane = PAIR ? frame_tmp : frame_tmp + (size_t)c * P.max_blocksize * LW;
 		if (MODE == DEC_SKIP && live)
 			sub_start[(size_t)j * P.channels + c] = r.err ? DEC_NO_START : r.wbase * 32 + br_pos(r);
 		pump_service(pm, r, L, tid, live, nwords);
@@ -1128,7 +1244,11 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 		}
 		return;
 	}
-	if (SUBM && only_c + 1 != P.channels) {
+	if constexpr (PAIR) {
+		// (the first channel's lanes have nothing to finish: a subframe the walk got through cannot fail here)
+		if (only_c + 1 != P.channels)
+			live = false;
+	} else if (SUBM && only_c + 1 != P.channels) {
 		// split: a subframe the walk got through cannot fail here (the same bits, the same checks).  Chained: this
 		// pass is the only one that looks at the subframe, so it says where the next one starts, or that the frame ends here
 		if (chained && have_frame && !live)
@@ -1164,7 +1284,13 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 		cands[j].end_byte = end_byte;
 		// a parse that ran off the end of the input is a cut-off frame, not a malformed one
 		cands[j].status = past ? 4u : r.err ? 2u : 1u;
-		cands[j].reserved = (!past && r.err && reserved_code) ? 1u : 0u;
+		uint32_t note = (!past && r.err && reserved_code) ? 1u : 0u;
+		if constexpr (PAIR) {
+			// bit 1: the frame's samples are in the output already (k_dec_output leaves it alone)
+			if (X.fkind[tid & (FPW - 1)] == 1)
+				note |= 2u;
+		}
+		cands[j].reserved = note;
 	}
 }
 
@@ -1172,9 +1298,10 @@ __global__ __launch_bounds__(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES, 2) vo
 // what every dec_frames_*.hip defines: the launch of its instance
 #define DEC_FRAMES_LAUNCHER(name, MODE, MAXLW, DEEP) \
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
-	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st) \
+	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, const uint64_t *ahead, void *pcm_out, hipStream_t st) \
 	{ \
-		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW, DEEP>), dim3(nwaves), dim3(MODE == DEC_PIPE ? 2 * DEC_LANES : DEC_LANES), 0, st, P, words, streams, cands, ncand, tmp, lw, sub_start, chain); \
+		hipLaunchKernelGGL((k_dec_frames<MODE, MAXLW, DEEP>), dim3(nwaves), dim3((MODE == DEC_PIPE || MODE == DEC_PAIR) ? 2 * DEC_LANES : DEC_LANES), 0, st, P, words, streams, \
+		                   cands, ncand, tmp, lw, sub_start, chain, ahead, pcm_out); \
 	}
 
 #endif

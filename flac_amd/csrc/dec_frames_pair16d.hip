@@ -1,0 +1,4 @@
+// One instance of the frame decoder kernel (see dec_frames.h for why each has a file of its own).
+#include "dec_frames.h"
+
+DEC_FRAMES_LAUNCHER(fa_dec_frames_pair16d, DEC_PAIR, 16, true)

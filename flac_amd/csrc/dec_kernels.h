@@ -47,7 +47,7 @@ struct FaFrameCand {
 	uint32_t assignment;
 	uint32_t stream;
 	uint32_t status;     // 0 not decoded, 1 good, 2 structure error, 3 CRC-16 mismatch, 4 cut off by the end of input
-	uint32_t reserved;   // keeps the row the size and layout of flacamd_frame_info
+	uint32_t reserved;   // bit 0, with status 2: the parse stopped at a reserved code; bit 1: the frame's samples are in the output already
 };
 
 hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
@@ -57,8 +57,12 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
                         uint32_t *ncand, unsigned long long *result, hipStream_t st);
 // sub_start: max_frames * channels words, the bit position at which each (frame, channel)'s subframe starts.
 // split: a walk that leaves every start, then a lane per subframe in one launch; else one launch per channel
+// pair (with split, two channels, fa_dec_pair_fits): P.lw is frames per group and a workgroup takes both channels of them and writes
+// final PCM to `out` for the frames whose CRC-16 the pass that ran ahead found right (`ahead`, complete after `before_sub`)
+bool fa_dec_pair_fits(uint32_t channels, uint32_t max_frames, uint32_t frames_per_group);
 void fa_dec_launch_frames(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st);
+                          int32_t *tmp, uint64_t *sub_start, bool split, bool pair, const uint64_t *ahead, hipEvent_t before_sub, void *out,
+                          hipStream_t st);
 // before_frames: CRC-16 of every header's frame on the guess that it ends where the next header was found, into `ahead`
 // (max_frames words; runs beside the frame decoder); else the pass after the frame decoder, which takes from `ahead`
 // (may be null) what was guessed right

@@ -577,6 +577,14 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 		}
 	}
 	__syncthreads();
+	// (frames the frame decoder wrote itself, FaFrameCand.reserved bit 1, are none of this kernel's business: mostly all of them)
+	{
+		bool work = false;
+		for (uint32_t fl = 0; fl < LW; fl++)
+			work = work || (sc[fl].status == 1 && !(sc[fl].reserved & 2u));
+		if (!work)
+			return;
+	}
 	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * LW;
 	const uint32_t row = tile_samples * ch;  // elements per frame in the tile
 	if (ch == 2 && LW >= 4) {
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 #pragma unroll
 			for (int j = 0; j < 4; j++) {
 				const uint32_t fl = fl0 + j;
-				if (!(sc[fl].status == 1 && i < sc[fl].blocksize))
+				if (!(sc[fl].status == 1 && !(sc[fl].reserved & 2u) && i < sc[fl].blocksize))
 					continue;
 				const uint32_t assignment = sc[fl].assignment;
 				int32_t a = av[j], b = bv[j];
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 	for (uint32_t idx = tid; idx < tile_samples * LW; idx += 256) {
 		const uint32_t fl = idx & (LW - 1), ii = idx >> lw_log;
 		const uint32_t i = i0 + ii;
-		if (!(sc[fl].status == 1 && i < sc[fl].blocksize))
+		if (!(sc[fl].status == 1 && !(sc[fl].reserved & 2u) && i < sc[fl].blocksize))
 			continue;
 		const uint32_t assignment = sc[fl].assignment;
 		if (ch == 2 && assignment != 0) {
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 	__syncthreads();
 	for (uint32_t fl = wv; fl < LW; fl += 4) {
 		const FaFrameCand &cf = sc[fl];
-		if (cf.status != 1 || i0 >= cf.blocksize)
+		if (cf.status != 1 || (cf.reserved & 2u) || i0 >= cf.blocksize)
 			continue;
 		const FaStream st = streams[cf.stream];
 		// FLACAMD_FIRST_SAMPLE_AUTO (single stream): the first header found anchors the output
@@ -712,7 +720,7 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
 // the instances of k_dec_frames, each in a translation unit of its own (dec_frames_*.hip)
 #define DEC_FRAMES_DECL(name) \
 	void name(const FaDecParams &P, const uint32_t *words, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand, int32_t *tmp, uint32_t lw, \
-	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, hipStream_t st)
+	          uint64_t *sub_start, uint32_t nwaves, uint32_t chain, const uint64_t *ahead, void *pcm_out, hipStream_t st)
 DEC_FRAMES_DECL(fa_dec_frames_skip16);
 DEC_FRAMES_DECL(fa_dec_frames_skip16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub16);
@@ -720,10 +728,24 @@ DEC_FRAMES_DECL(fa_dec_frames_sub16d);
 DEC_FRAMES_DECL(fa_dec_frames_sub32);
 DEC_FRAMES_DECL(fa_dec_frames_pipe16);
 DEC_FRAMES_DECL(fa_dec_frames_pipe16d);
+DEC_FRAMES_DECL(fa_dec_frames_pair16);
+DEC_FRAMES_DECL(fa_dec_frames_pair16d);
 
-// split: walk, then every (frame, channel) at once; else one launch per channel, in order (see dec_frames.h)
+// Whether the split form's subframe launch can take both channels of a stereo frame into one workgroup and write final
+// PCM itself (DEC_PAIR): two channels, P.lw frames per group with 2 x P.lw <= 16 columns, every workgroup resident at once.
+bool fa_dec_pair_fits(uint32_t channels, uint32_t max_frames, uint32_t frames_per_group)
+{
+	if (channels != 2 || frames_per_group < 1 || frames_per_group > 8)
+		return false;
+	return (max_frames + frames_per_group - 1) / frames_per_group <= 256 * 6;
+}
+
+// split: walk, then every (frame, channel) at once; else one launch per channel, in order (see dec_frames.h).
+// pair (with split, two channels): P.lw is frames per group, a workgroup takes both channels of them; `ahead` is what the
+// CRC pass that ran ahead left, `before_sub` (may be null) the event after which it is complete, `out` the caller's PCM.
 void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaStream *streams, FaFrameCand *cands, const uint32_t *ncand,
-                          int32_t *tmp, uint64_t *sub_start, bool split, hipStream_t st)
+                          int32_t *tmp, uint64_t *sub_start, bool split, bool pair, const uint64_t *ahead, hipEvent_t before_sub, void *out,
+                          hipStream_t st)
 {
 	FaDecParams P = Pin;
 	const uint32_t groups = (P.max_frames + P.lw - 1) / P.lw;
@@ -741,7 +763,15 @@ void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaS
 	if (split && P.channels >= 2 && P.lw <= 16 && P.skip_lw <= 16) {
 		const uint32_t walk_waves = (P.max_frames + P.skip_lw - 1) / P.skip_lw, sub_waves = groups * P.channels;
 		P.run = walk_waves <= deep_waves ? 64u : shallow_run;
-		(walk_waves <= deep_waves ? fa_dec_frames_skip16d : fa_dec_frames_skip16)(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, walk_waves, 0xffffffffu, st);
+		(walk_waves <= deep_waves ? fa_dec_frames_skip16d : fa_dec_frames_skip16)(P, words, streams, cands, ncand, tmp, P.skip_lw, sub_start, walk_waves, 0xffffffffu, nullptr, nullptr, st);
+		if (pair && fa_dec_pair_fits(P.channels, P.max_frames, P.lw)) {
+			if (before_sub)
+				(void)hipStreamWaitEvent(st, before_sub, 0);
+			const bool deep = groups <= 256 * 4;
+			P.run = deep ? 64u : shallow_run;
+			(deep ? fa_dec_frames_pair16d : fa_dec_frames_pair16)(P, words, streams, cands, ncand, tmp, 2 * P.lw, sub_start, groups, 0xffffffffu, ahead, out, st);
+			return;
+		}
 		// Two waves per subframe group (one reads, one restores) while all of them find room on the chip at once: 35 KB
 		// of LDS per workgroup with the deep ring, four to a CU; with the shallow ring the registers (147 per thread)
 		// allow six.  Measured (frames stage, one wave -> two): 16-bit stereo 256 frames 0.63 -> 0.50 ms, 6 460 frames
@@ -753,21 +783,21 @@ void fa_dec_launch_frames(const FaDecParams &Pin, const uint8_t *flac, const FaS
 		if (sub_waves <= pipe_groups) {
 			const bool deep = sub_waves <= 256 * 4;
 			P.run = deep ? 64u : shallow_run;
-			(deep ? fa_dec_frames_pipe16d : fa_dec_frames_pipe16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, st);
+			(deep ? fa_dec_frames_pipe16d : fa_dec_frames_pipe16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, nullptr, nullptr, st);
 			return;
 		}
 		P.run = sub_waves <= deep_waves ? 64u : shallow_run;
-		(sub_waves <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, st);
+		(sub_waves <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, sub_waves, 0xffffffffu, nullptr, nullptr, st);
 		return;
 	}
 	// the largest batches put 32 frames into a wave (twice the LDS, half the waves)
 	for (uint32_t c = 0; c < P.channels; c++) {
 		if (P.lw <= 16) {
 			P.run = groups <= deep_waves ? 64u : shallow_run;
-			(groups <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+			(groups <= deep_waves ? fa_dec_frames_sub16d : fa_dec_frames_sub16)(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, nullptr, nullptr, st);
 		} else {
 			P.run = 16;   // (32 lanes of a wave read 32 samples' worth of words faster than four refills per service point bring them)
-			fa_dec_frames_sub32(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, st);
+			fa_dec_frames_sub32(P, words, streams, cands, ncand, tmp, P.lw, sub_start, groups, c, nullptr, nullptr, st);
 		}
 	}
 }

@@ -1309,7 +1309,7 @@ bool next_frame(FLAC__StreamDecoder *d, bool *got_a_frame, bool do_full_decode)
 		if (f.status == 2) {
 			// malformed subframe data behind a good header: a reserved subframe type or residual coding
 			// method is "unparseable" (:2489,2500,2575,2654), anything else lost sync (:2476,2623,2728,2780)
-			send_error(d, f.reserved ? FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM : FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC);
+			send_error(d, (f.reserved & 1u) ? FLAC__STREAM_DECODER_ERROR_STATUS_UNPARSEABLE_STREAM : FLAC__STREAM_DECODER_ERROR_STATUS_LOST_SYNC);
 			// the reference then starts a fresh hunt where the parse stopped, which reports the bytes
 			// it has to skip on its own account
 			q->gap_reported = false;

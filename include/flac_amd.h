@@ -201,8 +201,9 @@ typedef struct {
 	uint32_t assignment; /* FLAC__ChannelAssignment */
 	uint32_t stream;
 	uint32_t status;
-	uint32_t reserved;   /* with status 2: 1 when the parse stopped at a reserved subframe type or
-	                        residual coding method (the reference's UNPARSEABLE_STREAM), else 0 */
+	uint32_t reserved;   /* bit 0, with status 2: the parse stopped at a reserved subframe type or residual coding
+	                        method (the reference's UNPARSEABLE_STREAM); bit 1 (internal): the frame decoder wrote the
+	                        frame's samples to the output itself */
 } flacamd_frame_info;
 /* What read_subframe_ (stream_decoder.c:2450-2713) learns about one subframe besides its samples: what the
  * reference's write callback finds in FLAC__Frame.subframes[] (consumed by `flac --analyze`, src/flac/analyze.c:63-144),

@@ -234,3 +234,58 @@ def test_split_and_lane_forms_agree_on_damaged_streams(monkeypatch, channels, bp
         assert a[1:4] == b[1:4], seed
         assert np.array_equal(a[0], b[0]), seed
         assert a[4] == b[4], seed
+
+
+def test_pair_form_decodes_every_stereo_golden_stream(monkeypatch):
+    """Large stereo batches in the split form take both channels of a frame into one workgroup, which writes final
+    interleaved PCM itself for the frames whose CRC-16 the pass that runs ahead has found right (no planes, no output
+    kernel for them).  FLAC_AMD_DEC_PAIR=2 selects that form from two frames up: every stereo golden stream comes back
+    exactly, at both output widths."""
+    import flac_amd
+    monkeypatch.setenv("FLAC_AMD_DEC_PAIR", "2")
+    seen = 0
+    for case in CASES:
+        if case["channels"] != 2:
+            continue
+        pcm, _meta, frames = golden_util.load_case(case)
+        blob = b"".join(frames)
+        for width in ((2, 4) if case["bps"] <= 16 else (4,)):
+            dec = flac_amd.Decoder(2, case["bps"], blocksize_of(case), device=0, max_input_bytes=len(blob) + 64, max_frames=len(frames) + 8)
+            try:
+                got, nfr, nwide, bad = dec.decode_host(blob, [(0, len(blob), 0, pcm.shape[0])], pcm.shape[0], out_sample_bytes=width)
+                rows = dec.frames()
+            finally:
+                dec.close()
+            assert (nfr, nwide, bad) == (len(frames), pcm.shape[0], 0), case["name"]
+            assert np.array_equal(got, pcm), case["name"]
+            assert all(r.reserved & 2 for r in rows), "%s: a frame did not take the direct way out" % case["name"]
+        seen += 1
+    assert seen > 10
+
+
+def test_pair_and_plane_forms_agree_on_damaged_streams(monkeypatch):
+    """Every second frame damaged: the pair form gives the samples, counts and per-frame records the plane form gives
+    (a damaged frame's CRC-16 is not right at its guessed end, so it goes the planes' way and is dropped there)."""
+    import flac_amd
+    channels, bps, rate, bs, level, nframes = 2, 16, 44100, 4096, 8, 32
+    pcm, frames = _synthetic_stream(channels, bps, rate, bs, level, nframes, 7 * bs + bps)
+    n = pcm.shape[0]
+    results = {}
+    for pair in ("0", "2"):
+        monkeypatch.setenv("FLAC_AMD_DEC_PAIR", pair)
+        dec = flac_amd.Decoder(channels, bps, bs, device=0, max_input_bytes=sum(map(len, frames)) + 64, max_frames=4 * nframes + 64)
+        try:
+            res = []
+            for seed in range(25):
+                rng = np.random.default_rng(2000 + seed)
+                blob = b"".join(_damage(f, rng) if k % 2 else f for k, f in enumerate(frames))
+                out, nfr, wide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=2)
+                info = dec.frames()
+                res.append((out.copy(), nfr, wide, bad, [(int(r.pos), int(r.status), int(r.end_byte) if r.status in (1, 3) else 0) for r in info]))
+            results[pair] = res
+        finally:
+            dec.close()
+    for seed, (a, b) in enumerate(zip(results["0"], results["2"])):
+        assert a[1:4] == b[1:4], seed
+        assert np.array_equal(a[0], b[0]), seed
+        assert a[4] == b[4], seed
