@@ -31,6 +31,7 @@ struct flacamd_decoder {
 	uint32_t *ncand;                // [0] count, [1] overflow flag
 	int32_t *tmp;
 	uint64_t *sub_start;            // bit position at which each (frame, channel)'s subframe starts
+	uint32_t planar;                // flacamd_decoder_set_planar_output
 	uint32_t pair;                  // split form, stereo: a workgroup takes both channels of lw frames and writes final PCM (DEC_PAIR)
 	uint32_t split, skip_lw;        // the split form (walk, then every subframe at once) is used, not a launch per channel; frames per wave of its walk
 	unsigned long long *result;     // good frames, wide samples, bad candidates
@@ -288,6 +289,8 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	P.flac_bytes = flac_bytes;
 	P.out_capacity_wide = out_capacity_wide;
 	P.subinfo = d->subinfo;
+	P.planar = d->planar;
+	P.pad = 0;
 	const bool prof = d->profiling != 0;
 	int evi = 0;
 #define STAGE_MARK() \
@@ -315,7 +318,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	STAGE_MARK();
 	// (the pair form needs the other stream's work - output cleared, CRC verdicts - before its second launch; otherwise
 	// the join comes after the frame decoder)
-	const bool pair = d->pair && d->side && (out_sample_bytes == 2 || out_sample_bytes == 4);
+	const bool pair = d->pair && d->side && !d->planar;
 	fa_dec_launch_frames(P, flac_dev, d->streams, d->cands, d->ncand, d->tmp, d->sub_start, d->split != 0, pair, d->crc_ahead,
 	                     pair ? d->ev_join : nullptr, pcm_out_dev, st);
 	if (d->side && !pair)
@@ -353,6 +356,14 @@ extern "C" int flacamd_decoder_enable_subframe_info(flacamd_decoder *d, int on)
 		(void)hipFree(d->subinfo);
 		d->subinfo = nullptr;
 	}
+	return FLACAMD_OK;
+}
+
+extern "C" int flacamd_decoder_set_planar_output(flacamd_decoder *d, int on)
+{
+	if (!d)
+		return fa_fail(FLACAMD_E_INVALID, "null decoder");
+	d->planar = on ? 1 : 0;
 	return FLACAMD_OK;
 }
 

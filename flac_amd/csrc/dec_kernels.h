@@ -18,6 +18,8 @@ struct FaDecParams {
 	uint64_t flac_bytes;
 	uint64_t out_capacity_wide;
 	FaSubInfo *subinfo;      // max_frames * channels records to fill, or null
+	uint32_t planar;         // 1: a frame's samples leave as [channel][blocksize] in the frame's stretch of the output, not interleaved
+	uint32_t pad;
 };
 
 // One record per (frame, channel) when the caller wants them: the layout of flacamd_subframe_info (include/flac_amd.h).

@@ -587,7 +587,8 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 	}
 	const int32_t *frame_tmp = tmp + (size_t)g * ch * P.max_blocksize * LW;
 	const uint32_t row = tile_samples * ch;  // elements per frame in the tile
-	if (ch == 2 && LW >= 4) {
+	const bool planar = P.planar != 0;
+	if (ch == 2 && LW >= 4 && !planar) {
 		// stereo, the common case: four frames' values of one sample are 16 bytes of each plane, and a
 		// frame's left/right pair goes to LDS as one word (int16 output) or two
 		const int32_t *pa = frame_tmp, *pb = frame_tmp + (size_t)P.max_blocksize * LW;
@@ -644,20 +645,22 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 				a = (mid + b) >> 1;
 				b = (mid - b) >> 1;
 			}
+			const uint32_t pa = planar ? fl * row + ii : fl * row + ii * 2, pb = planar ? fl * row + tile_samples + ii : pa + 1;
 			if (sb == 2) {
-				((int16_t *)lds)[fl * row + ii * 2] = (int16_t)a;
-				((int16_t *)lds)[fl * row + ii * 2 + 1] = (int16_t)b;
+				((int16_t *)lds)[pa] = (int16_t)a;
+				((int16_t *)lds)[pb] = (int16_t)b;
 			} else {
-				((int32_t *)lds)[fl * row + ii * 2] = a;
-				((int32_t *)lds)[fl * row + ii * 2 + 1] = b;
+				((int32_t *)lds)[pa] = a;
+				((int32_t *)lds)[pb] = b;
 			}
 		} else {
 			for (uint32_t c = 0; c < ch; c++) {
 				const int32_t v = frame_tmp[((size_t)c * P.max_blocksize + i) * LW + fl];
+				const uint32_t at = planar ? fl * row + c * tile_samples + ii : fl * row + ii * ch + c;
 				if (sb == 2)
-					((int16_t *)lds)[fl * row + ii * ch + c] = (int16_t)v;
+					((int16_t *)lds)[at] = (int16_t)v;
 				else
-					((int32_t *)lds)[fl * row + ii * ch + c] = v;
+					((int32_t *)lds)[at] = v;
 			}
 		}
 	}
@@ -679,6 +682,25 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 			continue;
 		if (st.sample_offset + rel + nvalid > P.out_capacity_wide)
 			continue;
+		if (planar) {
+			// the frame's stretch of the output holds its channels one after the other: a run per channel
+			// (so the whole frame has to have its place, not just this tile)
+			const uint64_t frel = cf.sample - first;
+			if ((st.total_samples && frel + cf.blocksize > st.total_samples) || st.sample_offset + frel + cf.blocksize > P.out_capacity_wide)
+				continue;
+			const uint64_t fbase = (st.sample_offset + frel) * ch;
+			for (uint32_t c = 0; c < ch; c++) {
+				const uint64_t ob = fbase + (uint64_t)c * cf.blocksize + i0;
+				const uint32_t ls = fl * row + c * tile_samples;
+				for (uint32_t e = lane; e < nvalid; e += 64) {
+					if (sb == 2)
+						((int16_t *)out)[ob + e] = ((const int16_t *)lds)[ls + e];
+					else
+						((int32_t *)out)[ob + e] = ((const int32_t *)lds)[ls + e];
+				}
+			}
+			continue;
+		}
 		const uint64_t obase = (st.sample_offset + rel) * ch;
 		const uint32_t nel = nvalid * ch;
 		// 16 bytes per lane where the run starts on a 16-byte boundary on both sides, single samples for the rest

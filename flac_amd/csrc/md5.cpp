@@ -159,6 +159,45 @@ void fa_md5_accumulate_interleaved(FaMd5 *c, const int32_t *samples, size_t coun
 		fa_md5_update(c, buf, fill);
 }
 
+void fa_md5_accumulate_planes(FaMd5 *c, const int32_t *const *planes, unsigned channels, size_t wide, unsigned bps_bytes)
+{
+	if (channels == 1) {
+		fa_md5_accumulate_interleaved(c, planes[0], wide, bps_bytes);
+		return;
+	}
+	uint8_t buf[4096 + 8];
+	const size_t per = 4096 / (bps_bytes * channels);   // wide samples per buffer-full
+	for (size_t i = 0; i < wide;) {
+		const size_t n = wide - i < per ? wide - i : per;
+		for (unsigned ch = 0; ch < channels; ch++) {
+			const int32_t *s = planes[ch] + i;
+			uint8_t *o = buf + ch * bps_bytes;
+			const size_t step = (size_t)bps_bytes * channels;
+			if (bps_bytes == 2) {
+				for (size_t k = 0; k < n; k++) {
+					const uint16_t v = (uint16_t)s[k];
+					memcpy(o + k * step, &v, 2);
+				}
+			} else if (bps_bytes == 4) {
+				for (size_t k = 0; k < n; k++)
+					memcpy(o + k * step, s + k, 4);
+			} else if (bps_bytes == 3) {
+				for (size_t k = 0; k < n; k++) {
+					const uint32_t v = (uint32_t)s[k];
+					o[k * step] = (uint8_t)v;
+					o[k * step + 1] = (uint8_t)(v >> 8);
+					o[k * step + 2] = (uint8_t)(v >> 16);
+				}
+			} else {
+				for (size_t k = 0; k < n; k++)
+					o[k * step] = (uint8_t)s[k];
+			}
+		}
+		fa_md5_update(c, buf, n * bps_bytes * channels);
+		i += n;
+	}
+}
+
 void fa_md5_accumulate_container(FaMd5 *c, const void *samples, unsigned container_bytes, size_t count, unsigned bps_bytes)
 {
 	if (container_bytes == 4) {

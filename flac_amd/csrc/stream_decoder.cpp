@@ -15,10 +15,14 @@
 // (FLAC__Subframe_Fixed / _LPC.residual, FLAC__Subframe_Verbatim.data) point at zeros.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "flac_amd.h"
@@ -61,6 +65,22 @@ struct FLAC__StreamDecoderProtected {
 	FLAC__bool md5_checking;
 };
 
+// The MD5 of the decoded samples (FLAC__MD5Accumulate in write_audio_frame_to_client_, stream_decoder.c:2953) is serial
+// work over the whole stream, about as long as everything else the decoder does on the host: it runs on a thread of its
+// own, over the frames' samples where they lie in the decoded batch, in the order the frames are handed out.
+struct Md5Lane {
+	std::thread thread;
+	std::mutex mu;
+	std::condition_variable cv;
+	// count samples at p, interleaved; or, channels > 0, `count` wide samples per channel, channel c's at p + c * count
+	struct Job { const FLAC__int32 *p; size_t count; unsigned bytes_per_sample, channels; };
+	std::deque<Job> jobs;
+	uint64_t posted, finished;
+	bool quit, started;
+	FaMd5 *md5;
+	Md5Lane() : posted(0), finished(0), quit(false), started(false), md5(0) {}
+};
+
 struct FLAC__StreamDecoderPrivate {
 	FLAC__StreamDecoderReadCallback read_callback;
 	FLAC__StreamDecoderSeekCallback seek_callback;
@@ -82,6 +102,7 @@ struct FLAC__StreamDecoderPrivate {
 	FLAC__byte header_warmup[2], lookahead;
 	FLAC__bool do_md5_checking, internal_reset_hack, is_seeking;
 	FaMd5 md5;
+	Md5Lane *md5_lane;
 	FLAC__byte computed_md5sum[16];
 	FLAC__uint64 first_frame_offset, target_sample;
 	unsigned unparseable_frame_count;
@@ -113,6 +134,7 @@ struct FLAC__StreamDecoderPrivate {
 	std::vector<FLAC__int32> *no_residual;         // max blocksize zeros
 	size_t cursor;
 	bool batch_active, batch_eof, batch_cut, batch_full, want_subinfo;
+	bool planar;   // the device hands a frame's samples out channel by channel: the write callback's planes point into the batch
 	size_t batch_base, batch_len;   // the batch covers in[batch_base, batch_base+batch_len)
 	uint64_t walk_pos;              // bytes of the batch already accounted for
 	bool gap_reported;
@@ -911,8 +933,79 @@ void report_gap(FLAC__StreamDecoder *d, size_t from, size_t to)
 	q->gap_reported = !first;
 }
 
+void md5_worker(Md5Lane *m)
+{
+	for (;;) {
+		Md5Lane::Job job;
+		{
+			std::unique_lock<std::mutex> lk(m->mu);
+			m->cv.wait(lk, [&] { return m->quit || !m->jobs.empty(); });
+			if (m->jobs.empty())
+				return;
+			job = m->jobs.front();
+			m->jobs.pop_front();
+		}
+		if (job.channels) {
+			const FLAC__int32 *pl[FLAC__MAX_CHANNELS];
+			for (unsigned c = 0; c < job.channels; c++)
+				pl[c] = job.p + (size_t)c * job.count;
+			fa_md5_accumulate_planes(m->md5, pl, job.channels, job.count, job.bytes_per_sample);
+		} else
+			fa_md5_accumulate_interleaved(m->md5, job.p, job.count, job.bytes_per_sample);
+		{
+			std::lock_guard<std::mutex> lk(m->mu);
+			m->finished++;
+		}
+		m->cv.notify_all();
+	}
+}
+
+// the samples stay where they are until md5_drain has returned
+void md5_post(FLAC__StreamDecoderPrivate *q, const FLAC__int32 *p, size_t count, unsigned bytes_per_sample, unsigned channels)
+{
+	Md5Lane *m = q->md5_lane;
+	if (!m->started) {
+		m->md5 = &q->md5;
+		m->quit = false;
+		m->thread = std::thread(md5_worker, m);
+		m->started = true;
+	}
+	{
+		std::lock_guard<std::mutex> lk(m->mu);
+		m->jobs.push_back(Md5Lane::Job{p, count, bytes_per_sample, channels});
+		m->posted++;
+	}
+	m->cv.notify_all();
+}
+
+// everything posted has gone into the digest
+void md5_drain(FLAC__StreamDecoderPrivate *q)
+{
+	Md5Lane *m = q->md5_lane;
+	if (!m || !m->started)
+		return;
+	std::unique_lock<std::mutex> lk(m->mu);
+	m->cv.wait(lk, [&] { return m->finished == m->posted; });
+}
+
+void md5_stop(FLAC__StreamDecoderPrivate *q)
+{
+	Md5Lane *m = q->md5_lane;
+	if (!m || !m->started)
+		return;
+	md5_drain(q);
+	{
+		std::lock_guard<std::mutex> lk(m->mu);
+		m->quit = true;
+	}
+	m->cv.notify_all();
+	m->thread.join();
+	m->started = false;
+}
+
 void release_device(FLAC__StreamDecoderPrivate *q)
 {
+	md5_drain(q);   // (its jobs point into h_out)
 	if (q->dev)
 		flacamd_decoder_destroy(q->dev);
 	q->dev = 0;
@@ -989,6 +1082,11 @@ bool ensure_device(FLAC__StreamDecoder *d)
 		if (!(env && !strcmp(env, "0")) && flacamd_decoder_enable_subframe_info(q->dev, 1) != FLACAMD_OK)
 			return device_fail(d, "cannot create the device decoder");
 		q->want_subinfo = !(env && !strcmp(env, "0"));
+		// FLAC_AMD_DEC_PLANAR=0: interleaved samples from the device, taken apart per frame on the host
+		const char *pl = getenv("FLAC_AMD_DEC_PLANAR");
+		q->planar = !(pl && !strcmp(pl, "0"));
+		if (q->planar && flacamd_decoder_set_planar_output(q->dev, 1) != FLACAMD_OK)
+			return device_fail(d, "cannot create the device decoder");
 		q->rice_words->assign((size_t)2 * FLACAMD_SUBFRAME_PARAMS * FLAC__MAX_CHANNELS, 0u);
 		q->no_residual->assign((size_t)bs + 1, 0);
 	}
@@ -1132,6 +1230,7 @@ bool start_batch(FLAC__StreamDecoder *d)
 				used = end;
 		}
 	}
+	md5_drain(q);   // (the digest thread may still be reading the batch before this one)
 	if (used && hipMemcpy(q->h_out, q->d_out, (size_t)used * q->dev_channels * sizeof(FLAC__int32), hipMemcpyDeviceToHost) != hipSuccess) {
 		fprintf(stderr, "flac_amd: copy from the device failed\n");
 		d->protected_->state = FLAC__STREAM_DECODER_ABORTED;
@@ -1226,9 +1325,12 @@ FLAC__StreamDecoderWriteStatus write_audio_frame(FLAC__StreamDecoder *d, const F
 	}
 	if (!q->has_stream_info)
 		q->do_md5_checking = 0;
-	if (q->do_md5_checking)
-		fa_md5_accumulate_interleaved(&q->md5, interleaved, (size_t)frame->header.blocksize * frame->header.channels,
-		                              (frame->header.bits_per_sample + 7) / 8);
+	if (q->do_md5_checking) {
+		if (q->planar)
+			md5_post(q, interleaved, frame->header.blocksize, (frame->header.bits_per_sample + 7) / 8, frame->header.channels);
+		else
+			md5_post(q, interleaved, (size_t)frame->header.blocksize * frame->header.channels, (frame->header.bits_per_sample + 7) / 8, 0);
+	}
 	return q->write_callback(d, frame, q->plane_ptrs, q->client_data);
 }
 
@@ -1363,10 +1465,15 @@ bool next_frame(FLAC__StreamDecoder *d, bool *got_a_frame, bool do_full_decode)
 		if (f.status == 3) {
 			// :2105-2113
 			send_error(d, FLAC__STREAM_DECODER_ERROR_STATUS_FRAME_CRC_MISMATCH);
-			if (do_full_decode)
+			if (do_full_decode) {
+				md5_drain(q);   // (a frame with the same number may have been posted from these very samples)
 				memset(inter, 0, sizeof(FLAC__int32) * (size_t)f.blocksize * h.channels);
+			}
 		}
-		if (do_full_decode) {
+		if (do_full_decode && q->planar) {
+			for (unsigned c = 0; c < h.channels; c++)
+				q->plane_ptrs[c] = inter + (size_t)c * f.blocksize;
+		} else if (do_full_decode) {
 			const unsigned ch = h.channels, bs = f.blocksize;
 			if (ch == 1)
 				memcpy(q->planes[0], inter, sizeof(FLAC__int32) * bs);
@@ -1711,15 +1818,17 @@ FLAC__StreamDecoder *FLAC__stream_decoder_new(void)
 		d->private_->subinfo = new (std::nothrow) std::vector<flacamd_subframe_info>();
 		d->private_->rice_words = new (std::nothrow) std::vector<unsigned>();
 		d->private_->no_residual = new (std::nothrow) std::vector<FLAC__int32>();
+		d->private_->md5_lane = new (std::nothrow) Md5Lane();
 	}
 	if (!d->protected_ || !d->private_ || !d->private_->filter_ids || !d->private_->table || !d->private_->subinfo || !d->private_->rice_words ||
-	    !d->private_->no_residual) {
+	    !d->private_->no_residual || !d->private_->md5_lane) {
 		if (d->private_) {
 			delete d->private_->filter_ids;
 			delete d->private_->table;
 			delete d->private_->subinfo;
 			delete d->private_->rice_words;
 			delete d->private_->no_residual;
+			delete d->private_->md5_lane;
 		}
 		free(d->private_);
 		free(d->protected_);
@@ -1745,6 +1854,8 @@ void FLAC__stream_decoder_delete(FLAC__StreamDecoder *d)
 	delete q->subinfo;
 	delete q->rice_words;
 	delete q->no_residual;
+	md5_stop(q);
+	delete q->md5_lane;
 	free(d->private_);
 	free(d->protected_);
 	free(d);
@@ -1803,6 +1914,7 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *d)
 	if (d->protected_->state == FLAC__STREAM_DECODER_UNINITIALIZED)
 		return 1;
 	bool md5_failed = false;
+	md5_drain(q);
 	fa_md5_final(&q->md5, q->computed_md5sum);
 	if (q->has_seek_table && q->seek_table.data.seek_table.points) {
 		free(q->seek_table.data.seek_table.points);
@@ -1964,6 +2076,7 @@ FLAC__bool FLAC__stream_decoder_reset(FLAC__StreamDecoder *d)
 		q->has_seek_table = 0;
 	}
 	q->do_md5_checking = d->protected_->md5_checking;
+	md5_drain(q);
 	fa_md5_init(&q->md5, fa_md5_default_mode());
 	q->fixed_block_size = 0;
 	q->first_frame_offset = 0;

@@ -205,6 +205,11 @@ typedef struct {
 	                        method (the reference's UNPARSEABLE_STREAM); bit 1 (internal): the frame decoder wrote the
 	                        frame's samples to the output itself */
 } flacamd_frame_info;
+/* on: from the next decode on a frame's samples leave channel by channel - the frame's stretch of the output (blocksize x
+ * channels samples, where its interleaved samples would lie) holds channel 0's blocksize samples, then channel 1's, and so
+ * on - which is what the reference's write callback hands out (`const FLAC__int32 *const buffer[]`, stream_decoder.c:2913).
+ * Default: interleaved. */
+int flacamd_decoder_set_planar_output(flacamd_decoder *d, int on);
 /* What read_subframe_ (stream_decoder.c:2450-2713) learns about one subframe besides its samples: what the
  * reference's write callback finds in FLAC__Frame.subframes[] (consumed by `flac --analyze`, src/flac/analyze.c:63-144),
  * except for the residual itself, which stays on the device. */

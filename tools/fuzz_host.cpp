@@ -26,6 +26,7 @@ int flacamd_decode_streams(flacamd_decoder *, const uint8_t *, uint64_t, const f
 int flacamd_decoder_set_frame_number_scale(flacamd_decoder *, uint32_t) { return FLACAMD_E_UNSUPPORTED; }
 int flacamd_decoder_frames(flacamd_decoder *, flacamd_frame_info *, uint32_t, uint32_t *, int *) { return FLACAMD_E_UNSUPPORTED; }
 int flacamd_decoder_enable_subframe_info(flacamd_decoder *, int) { return FLACAMD_E_UNSUPPORTED; }
+int flacamd_decoder_set_planar_output(flacamd_decoder *, int) { return FLACAMD_E_UNSUPPORTED; }
 int flacamd_decoder_subframe_info(flacamd_decoder *, uint32_t, uint32_t, flacamd_subframe_info *) { return FLACAMD_E_UNSUPPORTED; }
 const char *flacamd_last_error(void) { return "no device in the fuzz build"; }
 int hipMalloc(void **, size_t) { return 2; }
