@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <mutex>
 #include <new>
@@ -141,6 +142,10 @@ struct FLAC__StreamDecoderPrivate {
 };
 
 namespace {
+
+// FLAC_AMD_DEC_TIMES=1: where a decoder's host time went, printed by finish() (a measurement aid)
+struct DecTimes { double setup, gather, to_dev, decode, from_dev; } g_times;
+inline double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 const FLAC__byte kId3[3] = {'I', 'D', '3'};
 
@@ -1087,7 +1092,7 @@ bool ensure_device(FLAC__StreamDecoder *d)
 		q->planar = !(pl && !strcmp(pl, "0"));
 		if (q->planar && flacamd_decoder_set_planar_output(q->dev, 1) != FLACAMD_OK)
 			return device_fail(d, "cannot create the device decoder");
-		q->rice_words->assign((size_t)2 * FLACAMD_SUBFRAME_PARAMS * FLAC__MAX_CHANNELS, 0u);
+		q->rice_words->assign(((size_t)2 << FLAC__MAX_RICE_PARTITION_ORDER) * FLAC__MAX_CHANNELS, 0u);
 		q->no_residual->assign((size_t)bs + 1, 0);
 	}
 	const size_t out_bytes = (size_t)q->out_cap_wide * ch * sizeof(FLAC__int32);
@@ -1145,6 +1150,8 @@ bool start_batch(FLAC__StreamDecoder *d)
 	const FLAC__StreamDecoderState entry_state = d->protected_->state;
 	compact_input(q);
 	const size_t start_fill = q->in_wr;
+	const double t_enter = now_s();
+	double t_setup = 0;
 	// read until the buffer holds a batch (or, while seeking, a few frames' worth)
 	for (;;) {
 		size_t goal = q->in_pinned ? q->in_cap : (size_t)65536;
@@ -1169,8 +1176,10 @@ bool start_batch(FLAC__StreamDecoder *d)
 		q->in_wr += bytes;
 		if (!q->in_pinned && q->in_wr >= 16) {
 			// first data of the frame phase: set the device up, which also swaps the buffer
+			const double t0 = now_s();
 			if (!ensure_device(d))
 				return false;
+			t_setup += now_s() - t0;
 		}
 	}
 	if (q->in_wr == 0 && q->input_eof) {
@@ -1191,11 +1200,16 @@ bool start_batch(FLAC__StreamDecoder *d)
 	if (!q->dev || q->batch_len < 6)
 		return true;  // no frame header anywhere in the buffer
 	(void)hipSetDevice(fa_stream_device());
+	const double t_gathered = now_s();
+	g_times.setup += t_setup;
+	g_times.gather += t_gathered - t_enter - t_setup;
 	if (hipMemcpy(q->d_in, q->in, q->batch_len, hipMemcpyHostToDevice) != hipSuccess) {
 		fprintf(stderr, "flac_amd: copy to the device failed\n");
 		d->protected_->state = FLAC__STREAM_DECODER_ABORTED;
 		return false;
 	}
+	const double t_up = now_s();
+	g_times.to_dev += t_up - t_gathered;
 	flacamd_stream_desc sd;
 	sd.byte_offset = 0;
 	sd.byte_length = q->batch_len;
@@ -1217,6 +1231,8 @@ bool start_batch(FLAC__StreamDecoder *d)
 		if (flacamd_decoder_subframe_info(q->dev, 0, n, q->subinfo->data()) != FLACAMD_OK)
 			return device_fail(d, "decode failed");
 	}
+	const double t_dec = now_s();
+	g_times.decode += t_dec - t_up;
 	// bring back the span of samples the good frames cover
 	uint64_t used = 0;
 	if (n) {
@@ -1236,6 +1252,7 @@ bool start_batch(FLAC__StreamDecoder *d)
 		d->protected_->state = FLAC__STREAM_DECODER_ABORTED;
 		return false;
 	}
+	g_times.from_dev += now_s() - t_dec;
 	return true;
 }
 
@@ -1281,18 +1298,26 @@ void fill_subframes(FLAC__StreamDecoderPrivate *q, const flacamd_subframe_info *
 		if (ecm) {
 			ecm->type = r.rice2 ? FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE2 : FLAC__ENTROPY_CODING_METHOD_PARTITIONED_RICE;
 			ecm->data.partitioned_rice.order = r.partition_order;
-			unsigned *par = q->rice_words->data() + (size_t)c * 2 * FLACAMD_SUBFRAME_PARAMS, *raw = par + FLACAMD_SUBFRAME_PARAMS;
+			// (room for the 2^15 partitions the format allows, since a reader trusts the order, not capacity_by_order)
+			const size_t most = (size_t)1 << FLAC__MAX_RICE_PARTITION_ORDER;
+			unsigned *par = q->rice_words->data() + (size_t)c * 2 * most, *raw = par + most;
 			const unsigned esc = r.rice2 ? 31u : 15u;
-			for (unsigned i = 0; i < FLACAMD_SUBFRAME_PARAMS; i++) {
-				const bool have = r.partition_order >= 31 ? false : i < (1u << r.partition_order);
-				const bool escaped = have && (r.params[i] & 0x80u);
-				par[i] = !have ? 0u : escaped ? esc : r.params[i];
+			// (a reader looks at 2^order entries; beyond the 256th there are none here)
+			const unsigned nparts = r.partition_order >= 8 ? (unsigned)FLACAMD_SUBFRAME_PARAMS : 1u << r.partition_order;
+			for (unsigned i = 0; i < nparts; i++) {
+				const bool escaped = (r.params[i] & 0x80u) != 0;
+				par[i] = escaped ? esc : r.params[i];
 				raw[i] = escaped ? (r.params[i] & 31u) : 0u;
+			}
+			if (r.partition_order > 8 && r.partition_order <= FLAC__MAX_RICE_PARTITION_ORDER) {
+				// a frame cut finer than the records reach: its first 256 partitions are shown, the rest read as parameter 0
+				memset(par + nparts, 0, sizeof(unsigned) * (((size_t)1 << r.partition_order) - nparts));
+				memset(raw + nparts, 0, sizeof(unsigned) * (((size_t)1 << r.partition_order) - nparts));
 			}
 			FLAC__EntropyCodingMethod_PartitionedRiceContents &ct = q->rice_contents[c];
 			ct.parameters = par;
 			ct.raw_bits = raw;
-			ct.capacity_by_order = 8;   // what the arrays hold: 2^8 partitions (a frame cut finer than that shows its first 256)
+			ct.capacity_by_order = FLAC__MAX_RICE_PARTITION_ORDER;
 			ecm->data.partitioned_rice.contents = &ct;
 		}
 	}
@@ -1914,7 +1939,14 @@ FLAC__bool FLAC__stream_decoder_finish(FLAC__StreamDecoder *d)
 	if (d->protected_->state == FLAC__STREAM_DECODER_UNINITIALIZED)
 		return 1;
 	bool md5_failed = false;
+	const double t_fin = now_s();
 	md5_drain(q);
+	if (getenv("FLAC_AMD_DEC_TIMES")) {
+		fprintf(stderr, "flac_amd decoder times: device set-up %.1f ms, gathering input %.1f, to the device %.1f, decode %.1f, from the device %.1f, "
+		        "waiting for the digest at the end %.1f\n", 1e3 * g_times.setup, 1e3 * g_times.gather, 1e3 * g_times.to_dev, 1e3 * g_times.decode,
+		        1e3 * g_times.from_dev, 1e3 * (now_s() - t_fin));
+		g_times = DecTimes();
+	}
 	fa_md5_final(&q->md5, q->computed_md5sum);
 	if (q->has_seek_table && q->seek_table.data.seek_table.points) {
 		free(q->seek_table.data.seek_table.points);
