@@ -1,6 +1,8 @@
 // C ABI of the frame engine: handle management, buffer sizing, kernel sequencing.
 #include <hip/hip_runtime.h>
 
+#include <emmintrin.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -497,18 +499,26 @@ extern "C" int flacamd_encode_frames_host(flacamd_encoder *e, const int32_t *pcm
 		if (!e->stage_host16 &&
 		    hipHostMalloc((void **)&e->stage_host16, sizeof(int16_t) * (size_t)e->max_frames * P.blocksize * P.channels, hipHostMallocDefault) != hipSuccess)
 			return fa_fail(FLACAMD_E_NOMEM, "pinned staging buffer: hipHostMalloc failed");
-		for (size_t i = 0; i < n; i++)
+		// (values keep their low 16 bits, as a cast does; eight samples per step)
+		size_t i = 0;
+		for (; i + 8 <= n; i += 8) {
+			__m128i a = _mm_loadu_si128((const __m128i *)(pcm + i)), b = _mm_loadu_si128((const __m128i *)(pcm + i + 4));
+			a = _mm_srai_epi32(_mm_slli_epi32(a, 16), 16);
+			b = _mm_srai_epi32(_mm_slli_epi32(b, 16), 16);
+			_mm_storeu_si128((__m128i *)(e->stage_host16 + i), _mm_packs_epi32(a, b));
+		}
+		for (; i < n; i++)
 			e->stage_host16[i] = (int16_t)pcm[i];
-		HIP_TRY(hipMemcpy(e->stage_pcm, e->stage_host16, sizeof(int16_t) * n, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpyAsync(e->stage_pcm, e->stage_host16, sizeof(int16_t) * n, hipMemcpyHostToDevice, nullptr));
 		container = 2;
 	} else
-		HIP_TRY(hipMemcpy(e->stage_pcm, pcm, sizeof(int32_t) * wide_samples * P.channels, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpyAsync(e->stage_pcm, pcm, sizeof(int32_t) * wide_samples * P.channels, hipMemcpyHostToDevice, nullptr));
 	uint32_t nf = 0;
 	int rc = flacamd_encode_frames(e, e->stage_pcm, container, wide_samples, first_frame, is_last, loose_state, e->stage_out, e->stage_out_bytes,
 	                               nullptr, nullptr, &nf, nullptr);
 	if (rc)
 		return rc;
-	HIP_TRY(hipDeviceSynchronize());
+	HIP_TRY(hipStreamSynchronize(nullptr));   // (this call's work is all on the null stream; other streams are not waited for)
 	rc = flacamd_encoder_status(e);
 	if (rc)
 		return rc;
