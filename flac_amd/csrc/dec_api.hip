@@ -302,8 +302,8 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	// Frames that fail their checks leave zeros, like the reference's zeroed blocks.  The frame decoder is a few long
 	// chains of dependent instructions and leaves most of the chip's bandwidth and issue slots idle: clearing the
 	// output and the CRC-16 of the frames (on the guess that each ends where the next header was found) run beside it
-	// on a second stream, forked and joined with events so that the caller's stream (or a graph captured from it)
-	// sees one ordered piece of work.
+	// on a second stream, forked and joined with events so that the caller's stream sees one ordered piece of
+	// work.
 	const size_t out_bytes = (size_t)out_capacity_wide * d->channels * out_sample_bytes;
 	if (!d->side)
 		HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, out_bytes, st));
