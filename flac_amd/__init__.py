@@ -192,6 +192,13 @@ class FrameInfo(C.Structure):
                 ("assignment", C.c_uint32), ("stream", C.c_uint32), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class SubframeInfo(C.Structure):
+    """flacamd_subframe_info"""
+    _fields_ = [("type", C.c_uint8), ("order", C.c_uint8), ("wasted_bits", C.c_uint8), ("precision", C.c_uint8), ("shift", C.c_int8),
+                ("partition_order", C.c_uint8), ("rice2", C.c_uint8), ("pad", C.c_uint8), ("constant", C.c_int32), ("pad2", C.c_uint32 * 2),
+                ("qlp_coeff", C.c_int32 * 32), ("warmup", C.c_int32 * 32), ("params", C.c_uint8 * 256)]
+
+
 class Decoder:
     """Batch frame decoder bound to one GPU; every stream shares channels / bits / max blocksize."""
 
@@ -212,6 +219,19 @@ class Decoder:
             self.close()
         except Exception:
             pass
+
+    def set_planar_output(self, on):
+        """flacamd_decoder_set_planar_output: a frame's stretch of the output holds its channels one after the other."""
+        _check(lib().flacamd_decoder_set_planar_output(self._h, 1 if on else 0))
+
+    def enable_subframe_info(self, on=True):
+        _check(lib().flacamd_decoder_enable_subframe_info(self._h, 1 if on else 0))
+
+    def subframe_info(self, first_frame, nframes):
+        """flacamd_decoder_subframe_info: `channels` SubframeInfo records per frame of the table of frames()."""
+        rows = (SubframeInfo * (nframes * self.channels))()
+        _check(lib().flacamd_decoder_subframe_info(self._h, first_frame, nframes, rows))
+        return [rows[i] for i in range(nframes * self.channels)]
 
     @staticmethod
     def stream_array(streams):

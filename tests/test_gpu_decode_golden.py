@@ -289,3 +289,102 @@ def test_pair_and_plane_forms_agree_on_damaged_streams(monkeypatch):
         assert a[1:4] == b[1:4], seed
         assert np.array_equal(a[0], b[0]), seed
         assert a[4] == b[4], seed
+
+
+def test_planar_output_holds_the_interleaved_samples_frame_by_frame():
+    """flacamd_decoder_set_planar_output: every frame's stretch of the output (blocksize x channels samples, where its
+    interleaved samples would lie) holds channel 0's samples, then channel 1's, ...; nothing else changes.  Every golden
+    stream, both output widths where they apply."""
+    import flac_amd
+    for case in CASES:
+        pcm, _meta, frames = golden_util.load_case(case)
+        blob = b"".join(frames)
+        ch, n = case["channels"], pcm.shape[0]
+        for width in ((2, 4) if case["bps"] <= 16 else (4,)):
+            dec = flac_amd.Decoder(ch, case["bps"], blocksize_of(case), device=0, max_input_bytes=len(blob) + 64, max_frames=len(frames) + 8)
+            try:
+                dec.set_planar_output(True)
+                got, nfr, nwide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=width)
+                rows = dec.frames()
+            finally:
+                dec.close()
+            assert (nfr, nwide, bad) == (len(frames), n, 0), case["name"]
+            flat = got.reshape(-1)
+            for r in rows:
+                s0, bs = int(r.sample), int(r.blocksize)
+                block = flat[s0 * ch:(s0 + bs) * ch].reshape(ch, bs)
+                assert np.array_equal(block.T, pcm[s0:s0 + bs]), "%s: frame at sample %d" % (case["name"], s0)
+
+
+def test_subframe_records_match_a_parse_of_the_subframe_headers():
+    """flacamd_decoder_subframe_info against a host-side parse of the same frames' subframe headers: type, wasted bits,
+    order, precision, quantization level, coefficients, warm-up samples, partition order and the first partition's Rice
+    parameter, read bit by bit from the stream as the format lays them out (stream_decoder.c:2450-2713)."""
+    import flac_amd
+
+    class Bits:
+        def __init__(self, data, pos):
+            self.d, self.p = data, pos
+        def get(self, n):
+            v = 0
+            for _ in range(n):
+                v = (v << 1) | ((self.d[self.p >> 3] >> (7 - (self.p & 7))) & 1)
+                self.p += 1
+            return v
+        def signed(self, n):
+            v = self.get(n)
+            return v - (1 << n) if n and v >> (n - 1) else v
+
+    checked = 0
+    for case in CASES:
+        if case["bps"] > 24 or checked >= 40:
+            continue
+        pcm, _meta, frames = golden_util.load_case(case)
+        blob = b"".join(frames)
+        ch = case["channels"]
+        dec = flac_amd.Decoder(ch, case["bps"], blocksize_of(case), device=0, max_input_bytes=len(blob) + 64, max_frames=len(frames) + 8)
+        try:
+            dec.enable_subframe_info()
+            dec.decode_host(blob, [(0, len(blob), 0, pcm.shape[0])], pcm.shape[0], out_sample_bytes=4)
+            rows = dec.frames()
+            recs = dec.subframe_info(0, len(rows))
+        finally:
+            dec.close()
+        # the first subframe of each of the first frames: its header follows the frame header directly
+        for k, r in enumerate(rows[:6]):
+            b = Bits(blob, (int(r.pos) + int(r.hdr_bytes)) * 8)
+            rec = recs[k * ch]
+            assert b.get(1) == 0
+            t = b.get(6)
+            wasted = 0
+            if b.get(1):
+                wasted = 1
+                while not b.get(1):
+                    wasted += 1
+            sbps = case["bps"] - wasted + (1 if r.assignment == 2 else 0)   # (right-side: the first subframe is the side channel)
+            assert rec.wasted_bits == wasted, case["name"]
+            if t == 0:
+                assert rec.type == 0 and rec.constant == b.signed(sbps)
+            elif t == 1:
+                assert rec.type == 1
+            elif 8 <= t <= 12:
+                order = t & 7
+                assert rec.type == 2 and rec.order == order
+                assert [rec.warmup[i] for i in range(order)] == [b.signed(sbps) for _ in range(order)]
+                method = b.get(2)
+                assert rec.rice2 == method and rec.partition_order == b.get(4)
+                assert rec.params[0] == b.get(5 if method else 4)
+            else:
+                order = (t & 31) + 1
+                assert t >= 32 and rec.type == 3 and rec.order == order
+                assert [rec.warmup[i] for i in range(order)] == [b.signed(sbps) for _ in range(order)]
+                prec = b.get(4) + 1
+                assert rec.precision == prec and rec.shift == b.signed(5)
+                assert [rec.qlp_coeff[i] for i in range(order)] == [b.signed(prec) for _ in range(order)]
+                method = b.get(2)
+                assert rec.rice2 == method and rec.partition_order == b.get(4)
+                p0 = b.get(5 if method else 4)
+                if p0 != (31 if method else 15):
+                    assert rec.params[0] == p0
+            checked += 1
+    assert checked >= 40
