@@ -215,72 +215,81 @@ __device__ bool parse_frame_header(const uint8_t *d, uint64_t p, const FaDecPara
 #define SYNC_THREADS 256
 
 // The counting pass: every byte position is tested for a frame header; what comes out is the number of
-// headers per 4 KiB block and, per wave, the mask of lanes (16-byte runs) that hold one.
-__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts)
+// headers per 4 KiB block and, per wave, the mask of lanes (16-byte runs) that hold one.  A workgroup takes
+// SYNC_SUB consecutive blocks, all their loads requested before the first is looked at (a workgroup per block
+// lived for one load: 1.4 TB/s; four blocks: the 46 MB of the bench stream in 38 -> 20 us).
+#define SYNC_SUB 4
+__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts, uint32_t nb)
 {
-	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t wsum[SYNC_SUB][4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint64_t p0 = ((uint64_t)blockIdx.x * SYNC_THREADS + tid) * SYNC_BYTES_PER_THREAD;
-	uint32_t n = 0;  // headers in this run (more than two real ones in 16 bytes cannot happen)
 	// the lane masks lie behind the counts, four 64-bit words per block
-	uint64_t *masks = (uint64_t *)(block_counts + ((gridDim.x + 1) & ~1u)) + (size_t)blockIdx.x * (SYNC_THREADS / 64);
+	uint64_t *masks = (uint64_t *)(block_counts + ((nb + 1) & ~1u));
 	// the thread's 16 bytes and the one after them, as five words; only positions that hold the
 	// two sync bytes are looked at further
-	uint32_t w[SYNC_BYTES_PER_THREAD / 4 + 1];
-	{
-		const uint32_t *dw = (const uint32_t *)d;
-		const uint64_t nwords = (P.flac_bytes + 3) / 4;
+	uint32_t w[SYNC_SUB][SYNC_BYTES_PER_THREAD / 4 + 1];
+	const uint32_t *dw = (const uint32_t *)d;
+	const uint64_t nwords = (P.flac_bytes + 3) / 4;
+	static_assert(SYNC_BYTES_PER_THREAD == 16, "one 16-byte load per thread");
 #pragma unroll
-		for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4 + 1; k++) {
-			const uint64_t idx = p0 / 4 + k;
-			w[k] = idx < nwords ? dw[idx] : 0u;
+	for (uint32_t sb = 0; sb < SYNC_SUB; sb++) {
+		const uint64_t p0 = (((uint64_t)blockIdx.x * SYNC_SUB + sb) * SYNC_THREADS + tid) * SYNC_BYTES_PER_THREAD;
+		if (p0 / 4 + 5 <= nwords && (((uintptr_t)d) & 15) == 0) {
+			// (the common case: the run and the word behind it lie inside the input)
+			const uint4 v = *(const uint4 *)(dw + p0 / 4);
+			w[sb][0] = v.x;
+			w[sb][1] = v.y;
+			w[sb][2] = v.z;
+			w[sb][3] = v.w;
+			w[sb][4] = dw[p0 / 4 + 4];
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4 + 1; k++) {
+				const uint64_t idx = p0 / 4 + k;
+				w[sb][k] = idx < nwords ? dw[idx] : 0u;
+			}
 		}
 	}
-	uint32_t hits = 0;
-	// most 16-byte runs hold no 0xff byte at all: one test per word (a byte of w is 0xff where the byte of ~w is zero)
-	uint32_t any_ff = 0;
 #pragma unroll
-	for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4; k++)
-		any_ff |= (~w[k] - 0x01010101u) & w[k] & 0x80808080u;
-	if (any_ff) {
+	for (uint32_t sb = 0; sb < SYNC_SUB; sb++) {
+		const uint32_t blk = blockIdx.x * SYNC_SUB + sb;
+		const uint64_t p0 = ((uint64_t)blk * SYNC_THREADS + tid) * SYNC_BYTES_PER_THREAD;
+		uint32_t n = 0;  // headers in this run (more than two real ones in 16 bytes cannot happen)
+		uint32_t hits = 0;
+		// most 16-byte runs hold no 0xff byte at all: one test per word (a byte of w is 0xff where the byte of ~w is zero)
+		uint32_t any_ff = 0;
 #pragma unroll
-		for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
-			const uint32_t b0 = (w[i / 4] >> (8 * (i % 4))) & 0xff;
-			const uint32_t b1 = (w[(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
-			if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
-				hits |= 1u << i;
+		for (uint32_t k = 0; k < SYNC_BYTES_PER_THREAD / 4; k++)
+			any_ff |= (~w[sb][k] - 0x01010101u) & w[sb][k] & 0x80808080u;
+		if (any_ff) {
+#pragma unroll
+			for (uint32_t i = 0; i < SYNC_BYTES_PER_THREAD; i++) {
+				const uint32_t b0 = (w[sb][i / 4] >> (8 * (i % 4))) & 0xff;
+				const uint32_t b1 = (w[sb][(i + 1) / 4] >> (8 * ((i + 1) % 4))) & 0xff;
+				if (b0 == 0xff && (b1 & 0xfe) == 0xf8)
+					hits |= 1u << i;
+			}
+		}
+		while (hits) {
+			const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
+			hits &= hits - 1;
+			const uint64_t p = p0 + i;
+			if (p >= P.flac_bytes)
+				break;
+			FaFrameCand c;
+			if (parse_frame_header(d, p, P, streams, c))
+				n++;
+		}
+		const uint64_t m1 = __ballot(n > 0), m2 = __ballot(n > 1);
+		if (lane == 0) {
+			if (blk < nb)
+				masks[(size_t)blk * (SYNC_THREADS / 64) + wv] = m1;
+			wsum[sb][wv] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
 		}
 	}
-	while (hits) {
-		const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
-		hits &= hits - 1;
-		const uint64_t p = p0 + i;
-		if (p >= P.flac_bytes)
-			break;
-		FaFrameCand c;
-		if (parse_frame_header(d, p, P, streams, c))
-			n++;
-	}
-	if (n > 2)
-		n = 2;
-	uint32_t inc = n;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = __shfl_up(inc, o, 64);
-		if (lane >= (uint32_t)o)
-			inc += t;
-	}
-	if (lane == 63)
-		wsum[wv] = inc;
 	__syncthreads();
-	uint32_t off = 0;
-	for (uint32_t w = 0; w < wv; w++)
-		off += wsum[w];
-	const uint64_t m = __ballot(n > 0);
-	if (lane == 0)
-		masks[wv] = m;
-	if (tid == SYNC_THREADS - 1)
-		block_counts[blockIdx.x] = off + inc;
+	if (tid < SYNC_SUB && blockIdx.x * SYNC_SUB + tid < nb)
+		block_counts[blockIdx.x * SYNC_SUB + tid] = wsum[tid][0] + wsum[tid][1] + wsum[tid][2] + wsum[tid][3];
 }
 
 // The emitting pass: one thread per 4 KiB block of the counting pass.  It walks the block's lane
@@ -735,7 +744,7 @@ void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStrea
                         uint32_t *ncand, unsigned long long *result, hipStream_t st)
 {
 	const uint32_t nb = fa_dec_sync_blocks(P.flac_bytes);
-	hipLaunchKernelGGL(k_dec_sync, dim3(nb), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts);
+	hipLaunchKernelGGL(k_dec_sync, dim3((nb + SYNC_SUB - 1) / SYNC_SUB), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts, nb);
 	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, cands, ncand, nb, result);
 }
 
