@@ -77,9 +77,9 @@ struct Md5Lane {
 	struct Job { const FLAC__int32 *p; size_t count; unsigned bytes_per_sample, channels; };
 	std::deque<Job> jobs;
 	uint64_t posted, finished;
-	bool quit, started;
+	bool quit, started, failed;
 	FaMd5 *md5;
-	Md5Lane() : posted(0), finished(0), quit(false), started(false), md5(0) {}
+	Md5Lane() : posted(0), finished(0), quit(false), started(false), failed(false), md5(0) {}
 };
 
 struct FLAC__StreamDecoderPrivate {
@@ -969,11 +969,25 @@ void md5_worker(Md5Lane *m)
 void md5_post(FLAC__StreamDecoderPrivate *q, const FLAC__int32 *p, size_t count, unsigned bytes_per_sample, unsigned channels)
 {
 	Md5Lane *m = q->md5_lane;
-	if (!m->started) {
+	if (!m->started && !m->failed) {
 		m->md5 = &q->md5;
 		m->quit = false;
-		m->thread = std::thread(md5_worker, m);
-		m->started = true;
+		try {
+			m->thread = std::thread(md5_worker, m);
+			m->started = true;
+		} catch (...) {
+			m->failed = true;   // no thread to be had: the digest is worked out here
+		}
+	}
+	if (!m->started) {
+		if (channels) {
+			const FLAC__int32 *pl[FLAC__MAX_CHANNELS];
+			for (unsigned c = 0; c < channels; c++)
+				pl[c] = p + (size_t)c * count;
+			fa_md5_accumulate_planes(&q->md5, pl, channels, count, bytes_per_sample);
+		} else
+			fa_md5_accumulate_interleaved(&q->md5, p, count, bytes_per_sample);
+		return;
 	}
 	{
 		std::lock_guard<std::mutex> lk(m->mu);
