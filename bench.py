@@ -14,7 +14,7 @@ stream of the configuration is cut into contiguous frame ranges over the ranks (
 times longer instead).  --config C5 is the batch decode: 10 000 five-second `-8` streams (100 distinct signals x
 100 copies, --streams to change the count) dealt round-robin over the ranks, nothing exchanged.
 
-Rank 0 prints one JSON line; see DESIGN.md for what each field is computed from.
+Rank 0 prints one JSON line.
 """
 import argparse
 import ctypes as C
