@@ -602,20 +602,40 @@ __device__ __forceinline__ void pipe_flush(LDS &L, PX &X, const PipeOut &O, uint
 		static_assert(DEC_LANES % LDS::maxlw == 0, "a thread stays with one column");
 		if (col < LW) {
 			const uint32_t col_wasted = X.wasted[col];
-			const uint32_t lim = n * LDS::maxlw;
-			for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
-				int32_t v[8];
+			// thread t takes samples t / 16, t / 16 + 4, ... of its column; a run is 16, 32 or 64 samples but for a block's
+			// last one, and goes out in chunks of those sizes with every load requested before the first store
+			constexpr uint32_t per = DEC_LANES / LDS::maxlw;   // samples a step of the wave covers
+			const uint32_t s0 = tid / LDS::maxlw;
+			const int32_t *src = &L.out[s0 * ostride + col];
+			int32_t *dst = O.plane + (size_t)(i0 + s0) * LW + col;
+			const size_t dstep = (size_t)per * LW;
+			auto chunk = [&](auto count) __attribute__((always_inline)) {
+				constexpr int N = decltype(count)::value;
+				int32_t v[N];
 #pragma unroll
-				for (uint32_t u = 0; u < 8; u++) {
-					const uint32_t e = e0 + u * DEC_LANES;
-					v[u] = e < lim ? L.out[(e / LDS::maxlw) * ostride + col] : 0;
-				}
+				for (int u = 0; u < N; u++)
+					v[u] = src[u * per * ostride];
 #pragma unroll
-				for (uint32_t u = 0; u < 8; u++) {
-					const uint32_t e = e0 + u * DEC_LANES;
-					if (e < lim)
-						O.plane[(size_t)(i0 + (e / LDS::maxlw)) * LW + col] = (int32_t)((uint32_t)v[u] << col_wasted);
-				}
+				for (int u = 0; u < N; u++)
+					dst[u * dstep] = (int32_t)((uint32_t)v[u] << col_wasted);
+				src += N * per * ostride;
+				dst += N * dstep;
+			};
+			uint32_t base = 0;
+			for (; base + 16 * per <= n; base += 16 * per)
+				chunk(std::integral_constant<int, 16>());
+			if (base + 8 * per <= n) {
+				chunk(std::integral_constant<int, 8>());
+				base += 8 * per;
+			}
+			if (base + 4 * per <= n) {
+				chunk(std::integral_constant<int, 4>());
+				base += 4 * per;
+			}
+			for (; base + s0 < n; base += per) {
+				*dst = (int32_t)((uint32_t)*src << col_wasted);
+				src += per * ostride;
+				dst += dstep;
 			}
 		}
 	} else {
@@ -650,8 +670,29 @@ __device__ __forceinline__ void pipe_flush(LDS &L, PX &X, const PipeOut &O, uint
 	}
 }
 
+// N x 64 of the windows the reading wave handed over, cut into residuals in place: all N requested before the first is
+// used (an LDS round trip costs a lone wave as much as twenty instructions).  A thread that looks after a raw column
+// writes back what it read, so that no thread is ever masked out.
+template <int N>
+__device__ __forceinline__ void pipe_cut_chunk(int32_t *col, uint32_t k, bool mine)
+{
+	uint32_t win[N];
+#pragma unroll
+	for (int u = 0; u < N; u++)
+		win[u] = (uint32_t)col[u * DEC_LANES];
+#pragma unroll
+	for (int u = 0; u < N; u++) {
+		const uint32_t z = (uint32_t)__clz((int)win[u]);
+		const uint32_t lsbs = __builtin_amdgcn_ubfe(win[u], 31u - z - k, k);
+		const uint32_t uf = (z << k) | lsbs;
+		const int32_t v = (int32_t)(uf >> 1) ^ -(int32_t)(uf & 1u);
+		col[u * DEC_LANES] = mine ? v : (int32_t)win[u];
+	}
+}
+
 // Rice symbols that were handed over as they lie in the stream: thread t looks after the words of lane t mod 16,
-// four samples at a time (bitreader.c:775: zeros up to the stop bit, then the parameter's worth of low bits; zigzag)
+// four samples apart (bitreader.c:775: zeros up to the stop bit, then the parameter's worth of low bits; zigzag).
+// A run is 16, 32 or 64 samples but for a block's last one: 256, 512 or 1024 words, taken in chunks of those sizes.
 template <typename LDS, typename PX>
 __device__ __forceinline__ void pipe_cut_symbols(PX &X, uint32_t hand, uint32_t n, uint32_t tid)
 {
@@ -662,22 +703,26 @@ __device__ __forceinline__ void pipe_cut_symbols(PX &X, uint32_t hand, uint32_t 
 		const uint32_t k = kf & 31u;
 		const bool mine = !(kf & PIPE_RAW);
 		const uint32_t lim = n * xstride;
-		// eight words at a time, all requested before the first is used (an LDS round trip costs a lone wave as much
-		// as twenty instructions)
-		for (uint32_t e0 = tid; e0 < lim; e0 += 8 * DEC_LANES) {
-			uint32_t win[8];
-#pragma unroll
-			for (uint32_t u = 0; u < 8; u++)
-				win[u] = e0 + u * DEC_LANES < lim ? (uint32_t)X.res[hand][e0 + u * DEC_LANES] : 0u;
-#pragma unroll
-			for (uint32_t u = 0; u < 8; u++) {
-				const uint32_t z = (uint32_t)__clz((int)win[u]);
-				const uint32_t lsbs = __builtin_amdgcn_ubfe(win[u], 31u - z - k, k);
-				const uint32_t uf = (z << k) | lsbs;
-				const int32_t v = (int32_t)(uf >> 1) ^ -(int32_t)(uf & 1u);
-				if (mine && e0 + u * DEC_LANES < lim)
-					X.res[hand][e0 + u * DEC_LANES] = v;
-			}
+		int32_t *col = &X.res[hand][tid];
+		uint32_t base = 0;
+		for (; base + 16 * DEC_LANES <= lim; base += 16 * DEC_LANES)
+			pipe_cut_chunk<16>(col + base, k, mine);
+		if (base + 8 * DEC_LANES <= lim) {
+			pipe_cut_chunk<8>(col + base, k, mine);
+			base += 8 * DEC_LANES;
+		}
+		if (base + 4 * DEC_LANES <= lim) {
+			pipe_cut_chunk<4>(col + base, k, mine);
+			base += 4 * DEC_LANES;
+		}
+		// what is left of a block's last run: fewer than sixteen samples
+		for (; base + tid < lim; base += DEC_LANES) {
+			const uint32_t win = (uint32_t)col[base];
+			const uint32_t z = (uint32_t)__clz((int)win);
+			const uint32_t lsbs = __builtin_amdgcn_ubfe(win, 31u - z - k, k);
+			const uint32_t uf = (z << k) | lsbs;
+			if (mine)
+				col[base] = (int32_t)(uf >> 1) ^ -(int32_t)(uf & 1u);
 		}
 	}
 }
@@ -734,7 +779,7 @@ __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, const PipeOut &O
 	uint32_t hand = 0;
 	for (uint32_t i0 = 0; i0 < bs_w;) {
 		__syncthreads();
-		const uint32_t n = X.cnt[hand];
+		const uint32_t n = __builtin_amdgcn_readfirstlane(X.cnt[hand]);   // (the same in every lane: loops over it are scalar)
 		pipe_cut_symbols<LDS>(X, hand, n, tid);
 		const int32_t *src = have ? &X.res[hand][f] : &X.dummy[0];
 #pragma nounroll
@@ -828,7 +873,7 @@ __device__ __forceinline__ void restore_run(LDS &L, PX &X, const PipeOut &O, uin
 	uint32_t hand = 0;
 	for (uint32_t i0 = 0; i0 < bs_w;) {
 		__syncthreads();
-		const uint32_t n = X.cnt[hand];
+		const uint32_t n = __builtin_amdgcn_readfirstlane(X.cnt[hand]);   // (the same in every lane: loops over it are scalar)
 		pipe_cut_symbols<LDS>(X, hand, n, tid);
 		const int32_t *src = tid < LW ? &X.res[hand][tid] : &X.dummy[0];
 #pragma nounroll
