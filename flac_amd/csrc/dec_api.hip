@@ -23,6 +23,7 @@ struct flacamd_decoder {
 	uint32_t max_streams;
 	FaStream *streams;
 	uint32_t *block_counts;
+	FaFrameCand *kept;              // the headers of each 4 KiB block as the counting pass parsed them
 	FaSubInfo *subinfo;             // one record per (frame, channel) once flacamd_decoder_enable_subframe_info asked for them
 	uint64_t *crc_ahead;            // per header: the CRC pass that runs beside the frame decoder leaves its guess and verdict here
 	hipStream_t side;               // that pass and the clearing of the output run here, between ev_fork and ev_join
@@ -51,6 +52,7 @@ extern "C" void flacamd_decoder_destroy(flacamd_decoder *d)
 	(void)hipSetDevice(d->device);
 	(void)hipFree(d->streams);
 	(void)hipFree(d->block_counts);
+	(void)hipFree(d->kept);
 	(void)hipFree(d->crc_ahead);
 	(void)hipFree(d->subinfo);
 	if (d->side)
@@ -130,6 +132,7 @@ extern "C" int flacamd_decoder_create(uint32_t channels, uint32_t bits_per_sampl
 			}
 		}
 	}
+	ALLOC(d->kept, sizeof(FaFrameCand) * FA_SYNC_KEEP * (size_t)nb);
 	ALLOC(d->cands, sizeof(FaFrameCand) * max_frames);
 	ALLOC(d->ncand, 16);
 	ALLOC(d->tmp, sizeof(int32_t) * groups * 64 * channels * max_blocksize);
@@ -307,7 +310,7 @@ extern "C" int flacamd_decode_streams(flacamd_decoder *d, const uint8_t *flac_de
 	const size_t out_bytes = (size_t)out_capacity_wide * d->channels * out_sample_bytes;
 	if (!d->side)
 		HIP_TRY(hipMemsetAsync(pcm_out_dev, 0, out_bytes, st));
-	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->cands, d->ncand, d->result, st);
+	fa_dec_launch_sync(P, flac_dev, d->streams, d->block_counts, d->kept, d->cands, d->ncand, d->result, st);
 	if (d->side) {
 		HIP_TRY(hipEventRecord(d->ev_fork, st));
 		HIP_TRY(hipStreamWaitEvent(d->side, d->ev_fork, 0));

@@ -55,8 +55,10 @@ struct FaFrameCand {
 hipError_t fa_dec_upload_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 uint32_t fa_dec_sync_blocks(uint64_t flac_bytes);
 // (also leaves the count of headers in ncand[0], the overflow flag in ncand[1], and clears the three counters of `result`)
-void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *cands,
-                        uint32_t *ncand, unsigned long long *result, hipStream_t st);
+// kept: FA_SYNC_KEEP rows per 4 KiB of input (fa_dec_sync_blocks), scratch between the two passes
+#define FA_SYNC_KEEP 8
+void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *kept,
+                        FaFrameCand *cands, uint32_t *ncand, unsigned long long *result, hipStream_t st);
 // sub_start: max_frames * channels words, the bit position at which each (frame, channel)'s subframe starts.
 // split: a walk that leaves every start, then a lane per subframe in one launch; else one launch per channel
 // pair (with split, two channels, fa_dec_pair_fits): P.lw is frames per group and a workgroup takes both channels of them and writes

@@ -218,11 +218,19 @@ __device__ bool parse_frame_header(const uint8_t *d, uint64_t p, const FaDecPara
 // headers per 4 KiB block and, per wave, the mask of lanes (16-byte runs) that hold one.  A workgroup takes
 // SYNC_SUB consecutive blocks, all their loads requested before the first is looked at (a workgroup per block
 // lived for one load: 1.4 TB/s; four blocks: the 46 MB of the bench stream in 38 -> 20 us).
+// The headers found are also kept as parsed, the first SYNC_KEEP of a block in the order the threads come by (`kept`,
+// SYNC_KEEP rows per block): the emitting pass then has nothing to read again and parse, only to put them in order.
 #define SYNC_SUB 4
-__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts, uint32_t nb)
+#define SYNC_KEEP 8
+__global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts, uint32_t nb,
+                                                           FaFrameCand *kept)
 {
 	__shared__ uint32_t wsum[SYNC_SUB][4];
+	__shared__ uint32_t nkept[SYNC_SUB];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid < SYNC_SUB)
+		nkept[tid] = 0;
+	__syncthreads();
 	// the lane masks lie behind the counts, four 64-bit words per block
 	uint64_t *masks = (uint64_t *)(block_counts + ((nb + 1) & ~1u));
 	// the thread's 16 bytes and the one after them, as five words; only positions that hold the
@@ -277,8 +285,14 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 			if (p >= P.flac_bytes)
 				break;
 			FaFrameCand c;
-			if (parse_frame_header(d, p, P, streams, c))
+			if (parse_frame_header(d, p, P, streams, c)) {
+				if (n < 2) {   // (what the emitting pass takes of a run)
+					const uint32_t slot = atomicAdd(&nkept[sb], 1u);
+					if (slot < SYNC_KEEP)
+						kept[(size_t)blk * SYNC_KEEP + slot] = c;
+				}
 				n++;
+			}
 		}
 		const uint64_t m1 = __ballot(n > 0), m2 = __ballot(n > 1);
 		if (lane == 0) {
@@ -298,7 +312,8 @@ __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const 
 // front of it: every workgroup adds up the counts before its own 256 (a few thousand words out of L2:
 // cheaper than a scan kernel of its own in between) and scans its own.
 __global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint8_t *d, const FaStream *streams, const uint32_t *block_counts,
-                                                      FaFrameCand *cands, uint32_t *ncand_out, uint32_t nb, unsigned long long *result)
+                                                      FaFrameCand *cands, uint32_t *ncand_out, uint32_t nb, unsigned long long *result,
+                                                      const FaFrameCand *kept)
 {
 	__shared__ uint64_t wsum[4], wpre[4];
 	const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -339,6 +354,25 @@ __global__ __launch_bounds__(256) void k_dec_sync_emit(FaDecParams P, const uint
 	}
 	if (count == 0)
 		return;
+	if (count <= SYNC_KEEP) {
+		// the counting pass kept them all: in order of position (a handful at most: selection by rank)
+		uint64_t pos[SYNC_KEEP];
+#pragma unroll
+		for (uint32_t i = 0; i < SYNC_KEEP; i++)
+			pos[i] = i < count ? kept[(size_t)b * SYNC_KEEP + i].pos : ~0ull;
+#pragma unroll
+		for (uint32_t i = 0; i < SYNC_KEEP; i++) {
+			if (i >= count)
+				break;
+			uint32_t rank = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < SYNC_KEEP; j++)
+				rank += pos[j] < pos[i] ? 1u : 0u;
+			if (at + rank < P.max_frames)
+				cands[at + rank] = kept[(size_t)b * SYNC_KEEP + i];
+		}
+		return;
+	}
 	const uint64_t *masks = (const uint64_t *)(block_counts + ((nb + 1) & ~1u)) + (size_t)b * (SYNC_THREADS / 64);
 	for (uint32_t wv = 0; wv < SYNC_THREADS / 64; wv++) {
 		uint64_t m = masks[wv];
@@ -740,12 +774,12 @@ uint32_t fa_dec_sync_blocks(uint64_t flac_bytes)
 	return (uint32_t)((flac_bytes + per - 1) / per);
 }
 
-void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *cands,
-                        uint32_t *ncand, unsigned long long *result, hipStream_t st)
+void fa_dec_launch_sync(const FaDecParams &P, const uint8_t *flac, const FaStream *streams, uint32_t *block_counts, FaFrameCand *kept,
+                        FaFrameCand *cands, uint32_t *ncand, unsigned long long *result, hipStream_t st)
 {
 	const uint32_t nb = fa_dec_sync_blocks(P.flac_bytes);
-	hipLaunchKernelGGL(k_dec_sync, dim3((nb + SYNC_SUB - 1) / SYNC_SUB), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts, nb);
-	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, cands, ncand, nb, result);
+	hipLaunchKernelGGL(k_dec_sync, dim3((nb + SYNC_SUB - 1) / SYNC_SUB), dim3(SYNC_THREADS), 0, st, P, flac, streams, block_counts, nb, kept);
+	hipLaunchKernelGGL(k_dec_sync_emit, dim3((nb + 255) / 256), dim3(256), 0, st, P, flac, streams, block_counts, cands, ncand, nb, result, kept);
 }
 
 // the instances of k_dec_frames, each in a translation unit of its own (dec_frames_*.hip)
