@@ -466,11 +466,14 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 // Tiles of AC_T steps are double-buffered: the global loads for the next tile are in flight while
 // the current one is computed.  16-bit stereo with mid/side and a single window (the common case)
 // has a dedicated staging path in which one 32-bit load yields the sample of all four signals of a
-// frame, i.e. of two task pairs.
+// frame, i.e. of two task pairs; stereo with mid/side out of 32-bit words has the same path with one
+// 64-bit load per wide sample, and the planes of k_planes one with a 32-bit load per task (the pair of a
+// row are neighbouring planes).  Any other format is staged element by element.
 // ---------------------------------------------------------------------------------------------
 #define AC_T 128          // steps per tile
 #define AC_MAXROWS 36     // task pairs per workgroup at most (even)
-#define AC_FPW 5          // frames per wave in the dedicated staging path: ceil(AC_MAXROWS / 2 / 4)
+#define AC_FPW 5          // frames per wave in the dedicated staging paths for stereo: ceil(AC_MAXROWS / 2 / 4)
+#define AC_RPW 9          // rows per wave in the one for planes: AC_MAXROWS / 4
 #define AC_NK 3           // 64-lane strips per row: AC_T + 33 + 1 <= 192
 
 typedef float fa_f2 __attribute__((ext_vector_type(2)));
@@ -479,6 +482,8 @@ typedef float fa_f4 __attribute__((ext_vector_type(4)));
 // Wave priority: staging (global loads in flight, LDS stores, the barrier) runs ahead of the other workgroups'
 // multiply-add loops on the same SIMD, which only wait for LDS anyway (measured 0.157 -> 0.144 ms).
 #define APRIO(n) __builtin_amdgcn_s_setprio(n)
+enum { AC_PLAIN = 0, AC_QUAD16 = 1, AC_QUAD32 = 2, AC_PLANES = 3 };
+template <int MODE>
 __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, const void *pcm, const FaSubStat *stats,
                                                        const float *windows, float *autoc, uint32_t rows_per_block, uint32_t G)
 {
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 	// G lanes per row in each half of the workgroup: lags 2 g (threads 0..127) and 2 g + 1 (128..255)
 	const uint32_t odd = tid >> 7, my_j = (tid & 127) / G, my_l = 2 * ((tid & 127) % G) + odd;
 	const bool active = my_j < rows_per_block && row0 + my_j < nrows && my_l < lag;
-	const bool quad = B.pairs && P.nsignals == 4 && P.napod == 1;  // rows 2f, 2f+1 = (L,R), (M,S) of frame f
+	constexpr bool quad = MODE == AC_QUAD16 || MODE == AC_QUAD32;  // rows 2f, 2f+1 = (L,R), (M,S) of frame f
 	const uint32_t ntiles = (P.blocksize + AC_T - 1) / AC_T;
 	const uint32_t frames_pb = rows_per_block / 2, frame0 = row0 / 2;
 
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 			}
 		}
 	}
-	uint32_t q_w[AC_FPW][AC_NK];
+	uint32_t q_w[AC_FPW][AC_NK], q_w2[MODE == AC_QUAD32 ? AC_FPW : 1][AC_NK];
 	float q_win[AC_FPW][AC_NK];
 	auto quad_load = [&](uint32_t tile) {
 		const uint32_t c0 = tile * AC_T;
@@ -525,7 +530,12 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 			for (uint32_t m = 0; m < AC_NK; m++) {
 				const uint32_t idx = c0 + lane + 64 * m;
 				const uint32_t ci = q_bsf[n] ? umin32(idx, q_bsf[n] - 1) : 0;
-				q_w[n][m] = q_bsf[n] ? ((const uint32_t *)pcm)[(uint64_t)f * P.blocksize + ci] : 0u;
+				if (MODE == AC_QUAD32) {
+					const int2 lr = q_bsf[n] ? ((const int2 *)pcm)[(uint64_t)f * P.blocksize + ci] : int2{0, 0};
+					q_w[n][m] = (uint32_t)lr.x;
+					q_w2[n][m] = (uint32_t)lr.y;
+				} else
+					q_w[n][m] = q_bsf[n] ? ((const uint32_t *)pcm)[(uint64_t)f * P.blocksize + ci] : 0u;
 				q_win[n][m] = windows[umin32(idx, P.blocksize - 1)];
 			}
 		}
@@ -545,7 +555,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 				fa_f2 lr = {0.0f, 0.0f}, ms = {0.0f, 0.0f};
 				if (c0 + k < q_bsf[n]) {
 					const uint32_t w = q_w[n][m];
-					const int32_t l = (int32_t)(int16_t)(w & 0xffff), r = (int32_t)w >> 16;
+					const int32_t l = MODE == AC_QUAD32 ? (int32_t)w : (int32_t)(int16_t)(w & 0xffff);
+					const int32_t r = MODE == AC_QUAD32 ? (int32_t)q_w2[MODE == AC_QUAD32 ? n : 0][m] : (int32_t)w >> 16;
 					const float win = q_win[n][m];
 					lr.x = __fmul_rn((float)(l >> (q_wasted[n] & 0xff)), win);
 					lr.y = __fmul_rn((float)(r >> ((q_wasted[n] >> 8) & 0xff)), win);
@@ -554,6 +565,68 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 				}
 				*(fa_f2 *)(dst + ((size_t)(2 * fi) * row_pairs + k) * 2) = lr;
 				*(fa_f2 *)(dst + ((size_t)(2 * fi + 1) * row_pairs + k) * 2) = ms;
+			}
+		}
+	};
+	// planes: per row of this wave, the lengths of its two tasks' frames (0: no such task) and their wasted-bit counts
+	uint32_t r_bsf[AC_RPW], r_wasted[AC_RPW];
+	int32_t r_v[MODE == AC_PLANES ? AC_RPW : 1][AC_NK][2];
+	float r_win[AC_NK];
+	if (MODE == AC_PLANES) {
+#pragma unroll
+		for (uint32_t n = 0; n < AC_RPW; n++) {
+			const uint32_t j = wv + 4 * n, ta = 2 * (row0 + j);
+			r_bsf[n] = 0;
+			r_wasted[n] = 0;
+			if (j < rows_per_block && ta < ntasks) {
+				r_bsf[n] = frame_len(B, P.blocksize, ta / P.nsignals);
+				r_wasted[n] = stats[ta].wasted;
+				if (ta + 1 < ntasks) {
+					r_bsf[n] |= frame_len(B, P.blocksize, (ta + 1) / P.nsignals) << 16;
+					r_wasted[n] |= stats[ta + 1].wasted << 8;
+				}
+			}
+		}
+	}
+	auto rows_load = [&](uint32_t tile) {
+		const uint32_t c0 = tile * AC_T;
+#pragma unroll
+		for (uint32_t m = 0; m < AC_NK; m++)
+			r_win[m] = windows[umin32(c0 + lane + 64 * m, P.blocksize - 1)];
+#pragma unroll
+		for (uint32_t n = 0; n < AC_RPW; n++) {
+			const uint32_t j = wv + 4 * n;
+			if (j >= rows_per_block)
+				continue;
+			const int32_t *pa = (const int32_t *)pcm + (size_t)(2 * (row0 + j)) * P.blocksize;
+			const uint32_t la = r_bsf[n] & 0xffff, lb = r_bsf[n] >> 16;
+#pragma unroll
+			for (uint32_t m = 0; m < AC_NK; m++) {
+				const uint32_t idx = c0 + lane + 64 * m;
+				r_v[MODE == AC_PLANES ? n : 0][m][0] = la ? pa[umin32(idx, la - 1)] : 0;
+				r_v[MODE == AC_PLANES ? n : 0][m][1] = lb ? pa[P.blocksize + umin32(idx, lb - 1)] : 0;
+			}
+		}
+	};
+	auto rows_store = [&](uint32_t tile, float *dst) {
+		const uint32_t c0 = tile * AC_T;
+#pragma unroll
+		for (uint32_t n = 0; n < AC_RPW; n++) {
+			const uint32_t j = wv + 4 * n;
+			if (j >= rows_per_block)
+				continue;
+			const uint32_t la = r_bsf[n] & 0xffff, lb = r_bsf[n] >> 16;
+#pragma unroll
+			for (uint32_t m = 0; m < AC_NK; m++) {
+				const uint32_t k = lane + 64 * m;
+				if (k >= row_pairs)
+					continue;
+				fa_f2 ab = {0.0f, 0.0f};
+				if (c0 + k < la)
+					ab.x = __fmul_rn((float)(r_v[MODE == AC_PLANES ? n : 0][m][0] >> (r_wasted[n] & 0xff)), r_win[m]);
+				if (c0 + k < lb)
+					ab.y = __fmul_rn((float)(r_v[MODE == AC_PLANES ? n : 0][m][1] >> (r_wasted[n] >> 8)), r_win[m]);
+				*(fa_f2 *)(dst + ((size_t)j * row_pairs + k) * 2) = ab;
 			}
 		}
 	};
@@ -586,6 +659,9 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 	if (quad) {
 		quad_load(0);
 		quad_store(0, xs);
+	} else if (MODE == AC_PLANES) {
+		rows_load(0);
+		rows_store(0, xs);
 	} else
 		plain_stage(0, xs);
 	__syncthreads();
@@ -597,6 +673,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 		const bool more = t + 1 < ntiles;
 		if (more && quad)
 			quad_load(t + 1);
+		if (more && MODE == AC_PLANES)
+			rows_load(t + 1);
 		APRIO(0);
 		if (active) {
 			const float *row = cur_buf + (size_t)my_j * row_pairs * 2;
@@ -626,6 +704,8 @@ __global__ __launch_bounds__(FA_THREADS) void k_autoc(FaEncParams P, FaBatch B, 
 		if (more) {
 			if (quad)
 				quad_store(t + 1, next_buf);
+			else if (MODE == AC_PLANES)
+				rows_store(t + 1, next_buf);
 			else
 				plain_stage(t + 1, next_buf);
 		}
@@ -976,7 +1056,17 @@ void fa_launch_autoc(const FaEncParams &P, const FaBatch &B, const void *pcm, co
 	const uint32_t ntasks = B.nframes * P.nsignals * P.napod;
 	const uint32_t nrows = (ntasks + 1) / 2;
 	const size_t lds = (size_t)2 * rows * row_bytes;
-	hipLaunchKernelGGL(k_autoc, dim3((nrows + rows - 1) / rows), dim3(FA_THREADS), lds, st, P, B, pcm, stats, windows, autoc, rows, G);
+	const dim3 grid((nrows + rows - 1) / rows), block(FA_THREADS);
+	// (a frame is at most 65 535 samples: the planes' path keeps two lengths in a word)
+	const bool ms4 = P.nsignals == 4 && P.napod == 1;
+	if (B.pairs && ms4)
+		hipLaunchKernelGGL(k_autoc<AC_QUAD16>, grid, block, lds, st, P, B, pcm, stats, windows, autoc, rows, G);
+	else if (!B.pairs && !B.planar && ms4 && P.channels == 2 && B.sample_bytes == 4 && ((uintptr_t)pcm & 7) == 0)
+		hipLaunchKernelGGL(k_autoc<AC_QUAD32>, grid, block, lds, st, P, B, pcm, stats, windows, autoc, rows, G);
+	else if (B.planar && P.napod == 1 && P.nsignals == P.channels && P.blocksize <= 65535)
+		hipLaunchKernelGGL(k_autoc<AC_PLANES>, grid, block, lds, st, P, B, pcm, stats, windows, autoc, rows, G);
+	else
+		hipLaunchKernelGGL(k_autoc<AC_PLAIN>, grid, block, lds, st, P, B, pcm, stats, windows, autoc, rows, G);
 }
 
 void fa_launch_lpc(const FaEncParams &P, const FaBatch &B, const FaSubStat *stats, const float *autoc, FaLpcCand *cands, int32_t *coefs,
