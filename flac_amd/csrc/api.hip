@@ -233,7 +233,7 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 	ALLOC(e->cands, sizeof(FaLpcCand) * F * S * P.ncand);
 	ALLOC(e->coefs, sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order + 64);   // slack: the wave search reads twelve coefficients per slot whatever the order
 	ALLOC(e->plans, sizeof(FaPlan) * F * S);
-	ALLOC(e->assign, sizeof(uint32_t) * (F + 2) + sizeof(uint64_t) * F);   // and the frame writer's placement tickets (run_batch)
+	ALLOC(e->assign, sizeof(uint32_t) * (F + 2) + sizeof(uint64_t) * F * (1 + p.channels));   // and the frame writers' tickets (run_batch)
 	ALLOC(e->slots, (size_t)P.slot_bytes * F + 64);
 	// Three or more interleaved channels: a workgroup that takes ONE channel out of them uses 4 of every 4 x channels
 	// bytes it fetches, and every channel's workgroup fetches every line.  Such streams are laid out again first, frame
@@ -388,7 +388,7 @@ static int run_batch(const FaEncParams &P, const FaBatch &Bin, const EncWork &W,
 	// FLAC_AMD_STAMPS: per-workgroup cycle stamps of k_search land in the (by now consumed) autocorrelation buffer
 	fa_launch_search(P, B, pcm_dev, W.stats, W.cands, W.coefs, W.plans, (stamps_env && strcmp(stamps_env, "pack")) ? (unsigned long long *)W.autoc : nullptr, st);
 	STAGE_MARK();
-	// (the frame writer's placement tickets, one 64-bit word per frame, lie behind the assignments)
+	// (the frame writers' tickets lie behind the assignments: one 64-bit word per frame, then one per frame and channel)
 	unsigned long long *tickets = (unsigned long long *)(W.assign + ((B.nframes + 1) & ~1u));
 	fa_launch_decide(P, B, W.plans, W.assign, W.errflag + 1, tickets, st);
 	STAGE_MARK();
@@ -578,7 +578,7 @@ StaticLayout static_layout(const FaEncParams &P, size_t F)
 	L.cands = take(sizeof(FaLpcCand) * F * S * P.ncand);
 	L.coefs = take(sizeof(int32_t) * F * S * P.ncand * P.max_lpc_order + 64);
 	L.plans = take(sizeof(FaPlan) * F * S);
-	L.assign = take(sizeof(uint32_t) * (F + 2) + sizeof(uint64_t) * F);
+	L.assign = take(sizeof(uint32_t) * (F + 2) + sizeof(uint64_t) * F * (1 + P.channels));
 	L.slots = take((size_t)P.slot_bytes * F + 64);
 	L.frame_bytes = take(sizeof(uint32_t) * F);
 	L.offsets = take(sizeof(uint64_t) * (F + 1));

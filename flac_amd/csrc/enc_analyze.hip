@@ -922,7 +922,13 @@ __global__ void k_decide(FaEncParams P, FaBatch B, const FaPlan *plans, uint32_t
 	const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= B.nframes)
 		return;
-	tickets[f] = 0;   // nothing known yet about where frame f goes (k_pack_frame)
+	tickets[f] = 0;   // nothing known yet about where frame f goes (k_pack_frame, k_pack_sub)
+	{
+		// nor about the pieces of it (k_pack_sub: two words per channel, behind the tickets)
+		uint2 *sub = (uint2 *)(tickets + B.nframes) + (size_t)f * P.channels;
+		for (uint32_t c = 0; c < P.channels; c++)
+			sub[c] = make_uint2(0, 0);
+	}
 	uint32_t ca = 0;
 	if (P.do_ms) {
 		if (P.loose_ms) {

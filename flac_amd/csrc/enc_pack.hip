@@ -481,6 +481,13 @@ __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
 	// ---- subframes in written order (stream_encoder.c:3091-3151) ----
 	for (uint32_t c = 0; c < P.channels; c++) {
+		{
+			// The fields in front of a subframe's codes are written once, not under drain(): they need room in the window now
+			// (at most 8 + 32 + 32 * 33 + 9 + 32 * 15 + 6 bits); what does not fit a window would be dropped.
+			const uint32_t bw = S.base_word;
+			if ((bitpos >> 5) + 64 > bw + PK_CAPW)
+				flush_window(S, slot, slot_words, (bitpos >> 5) - bw, true, true);
+		}
 		uint32_t sig = c;
 		if (ca == 1 && c == 1) sig = P.channels + 1;       // left, side
 		else if (ca == 2 && c == 0) sig = P.channels + 1;  // side, right
@@ -800,6 +807,10 @@ __device__ __forceinline__ void pq_emit(uint32_t *W, uint32_t q, uint32_t vh)
 
 __device__ __forceinline__ uint32_t pq_mask(uint32_t n) { return n >= 32 ? 0xffffffffu : (1u << n) - 1u; }
 
+template <int HIST, bool NARROW>
+__device__ __forceinline__ uint32_t pq_values_of(const int32_t (&d)[HIST + FA_CHUNK], const PqSub &D, const int32_t *qv, uint32_t base, uint32_t bsf, uint32_t k,
+                                                 bool pstart, int mode, uint32_t (&uz)[FA_CHUNK]);
+
 // What the thread codes for its sixteen samples of a subframe (uz: the zigzagged residual, or the sample
 // itself when verbatim) from the staged stereo words, and the length of its run in bits.  k: the Rice
 // parameter of the partition the samples lie in; pstart: they are its first, so the parameter precedes them.
@@ -836,6 +847,14 @@ __device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHU
 		for (int j = 0; j < HIST + FA_CHUNK; j++)
 			d[j] >>= D.wasted;
 	}
+	return pq_values_of<HIST, true>(d, D, qv, base, bsf, k, pstart, 0, uz);
+}
+
+// the same from the subframe's own samples (wasted bits gone); mode: the arithmetic an LPC residual needs (lpc_mode)
+template <int HIST, bool NARROW>
+__device__ __forceinline__ uint32_t pq_values_of(const int32_t (&d)[HIST + FA_CHUNK], const PqSub &D, const int32_t *qv, uint32_t base, uint32_t bsf, uint32_t k,
+                                                 bool pstart, int mode, uint32_t (&uz)[FA_CHUNK])
+{
 	if (D.type == FA_SUB_VERBATIM) {
 		const uint32_t mask = pq_mask(D.sbps);
 #pragma unroll
@@ -847,7 +866,7 @@ __device__ __forceinline__ uint32_t pq_values(const int32_t (&raw)[HIST + FA_CHU
 	if (D.type == FA_SUB_FIXED)
 		fixed_residual16<HIST>(d, D.order, res);
 	else
-		lpc_residual16_any<HIST, true>(d, qv, D.order, (int)D.shift, 0, res);
+		lpc_residual16_any<HIST, NARROW>(d, qv, D.order, (int)D.shift, mode, res);
 	uint32_t nb = pstart ? D.plen : 0u;
 	const uint32_t k1 = k + 1u;
 	// the frame's first `order` samples are the warm-up, and a short last block ends inside a chunk:
@@ -903,7 +922,8 @@ __device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint
 #define PQ_SUM (2ull << 62)
 #define PQ_VALUE ((1ull << 62) - 1)
 // WAIT = false: one look at the 64 tickets in front, no waiting; false if that does not settle it (nothing is published then).
-template <bool WAIT>
+// PUBLISH = false: only asks where frame f starts (for a workgroup that is not the one that knows the frame's size).
+template <bool WAIT, bool PUBLISH = true>
 __device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f, uint32_t size, uint32_t lane, uint64_t &place)
 {
 	uint64_t before = 0;
@@ -933,7 +953,7 @@ __device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f
 			break;
 		at -= 64;
 	}
-	if (lane == 0)
+	if (PUBLISH && lane == 0)
 		__hip_atomic_store(&tickets[f], PQ_SUM | (before + size), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	place = before;
 	return true;
@@ -1228,6 +1248,347 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 		frame_bytes[f] = nbytes + 2;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_pack_sub: the frame writer for every other stream whose blocks fit one pass (any channel count, any
+// sample width, with or without mid/side): a workgroup per WRITTEN SUBFRAME, so that a frame of eight
+// channels is eight workgroups side by side and not one that walks them in turn.  A workgroup's piece
+// of the frame is its subframe, with the frame header in front for the first channel and the padding
+// and CRC-16 behind for the last.  Pieces meet at any bit, so three things pass between the
+// workgroups of a frame, each through a word of `subt` (two per piece, cleared by k_decide):
+//   - the piece's length in bits, as soon as the scan over the code lengths has it; the pieces in
+//     front are then added up to find where this one starts, and its bits go into the LDS window at
+//     that position modulo 8, so that window bytes are output bytes;
+//   - the byte in which the piece ends, if it ends inside one: the next piece ORs it into its first
+//     byte and writes that byte, the piece itself writes whole bytes only;
+//   - the CRC-16 of the piece's bytes (own bits only, which is what makes the sum work: the CRC is
+//     linear).  The last channel's workgroup shifts every piece's CRC to the end of the frame
+//     (multiplication by a power of x) and XORs them.
+// The frame's place in the output comes from the tickets as in k_pack_frame: the last channel's
+// workgroup, which knows the frame's size, publishes it and later the running sum; the others only
+// ask.  Every wait is for a workgroup with a smaller index, and nobody waits before its length is
+// out, so the waits end.
+// ---------------------------------------------------------------------------------------------
+#define PS_VALID 0x80000000u
+
+template <int HIST>
+struct PsShared {
+	union {
+		uint32_t W[PQ_CAPW];
+		int32_t T[ST_WORDS(HIST)];
+	} u __attribute__((aligned(16)));
+	uint16_t crc_tables[4][256];
+	uint32_t crcs[4];
+	uint32_t scan[4];
+	uint8_t crc8[256] __attribute__((aligned(4)));
+	uint8_t params[FA_MAX_PARTS];
+	int32_t q[FA_MAX_ORDER];
+	uint64_t place;
+	uint32_t start_bit;   // of the piece, counted from the frame's first bit
+	uint32_t placed;
+};
+
+__device__ __forceinline__ uint32_t ps_wait(const uint32_t *word)
+{
+	uint32_t v;
+	while (!((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & PS_VALID))
+		__builtin_amdgcn_s_sleep(1);
+	return v;
+}
+
+template <int HIST, bool NARROW>
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PQ_WAVES, PQ_WAVES)))
+void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaPlan *__restrict__ plans,
+                const uint32_t *__restrict__ assign, uint32_t *__restrict__ frame_bytes, uint32_t *errflag, uint8_t *__restrict__ out,
+                uint64_t out_capacity, uint64_t *__restrict__ offsets, unsigned long long *tickets, uint32_t *subt)
+{
+	__shared__ PsShared<HIST> S;
+	const uint32_t ch = P.channels;
+	const uint32_t f = blockIdx.x / ch, c = blockIdx.x - f * ch, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const bool first_piece = c == 0, last_piece = c == ch - 1;
+	const uint32_t bsf = frame_len(B, P.blocksize, f);
+	const uint64_t frame_start = (uint64_t)f * P.blocksize;
+	constexpr uint32_t HP = ST_HP(HIST);
+	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
+	uint32_t *my_words = subt + 2 * (size_t)blockIdx.x;
+	const uint32_t *frame_words = subt + 2 * (size_t)f * ch;
+
+	// ---- which signal this subframe is (stream_encoder.c:3091-3151), and everything it needs from memory ----
+	const uint32_t ca = __builtin_amdgcn_readfirstlane(assign[f]);
+	uint32_t sig = c;
+	if (ca == 1 && c == 1) sig = ch + 1;       // left, side
+	else if (ca == 2 && c == 0) sig = ch + 1;  // side, right
+	else if (ca == 3) sig = ch + c;            // mid, side
+	const FaPlan *pl = plans + (size_t)f * P.nsignals + sig;
+	PqSub D;
+	int mode;
+	{
+		int32_t v[NIT];
+		stage_load<HIST>(v, pcm, ch, B.sample_bytes, fa_layout(B), frame_start, bsf, sig, 0);
+		const uint8_t pre_param = pl->params[tid];
+		const int32_t pre_q = tid < FA_MAX_ORDER ? pl->q[tid] : 0;
+		const uint4 hd = *(const uint4 *)pl;
+		const FaSubStat *st = stats + (size_t)f * P.nsignals + sig;
+		const uint32_t h1 = __builtin_amdgcn_readfirstlane(hd.y), h2 = __builtin_amdgcn_readfirstlane(hd.z);
+		D.sig = sig;
+		D.type = h1 & 0xff;
+		D.order = (h1 >> 8) & 0xff;
+		D.precision = (h1 >> 16) & 0xff;
+		D.shift = (uint32_t)(int32_t)(int8_t)(h1 >> 24);
+		D.po = h2 & 0xff;
+		D.rice2 = (h2 >> 8) & 0xff;
+		mode = (int)((h2 >> 16) & 0xff);
+		D.constant = __builtin_amdgcn_readfirstlane(hd.w);
+		D.wasted = __builtin_amdgcn_readfirstlane(st->wasted);
+		D.sbps = __builtin_amdgcn_readfirstlane(st->bps);
+		D.plen = D.rice2 ? 5 : 4;
+		D.psize = bsf >> D.po;
+		// FLAC__subframe_add_* (stream_encoder_framing.c:366-479)
+		D.hbits = 8 + D.wasted;
+		if (D.type == FA_SUB_CONSTANT)
+			D.hbits += D.sbps;
+		else if (D.type == FA_SUB_FIXED)
+			D.hbits += D.order * D.sbps + 6;
+		else if (D.type == FA_SUB_LPC)
+			D.hbits += D.order * (D.sbps + D.precision) + 9 + 6;
+		for (uint32_t e = tid; e < 4 * 256 / 2; e += FA_THREADS)
+			((uint32_t *)&S.crc_tables[0][0])[e] = ((const uint32_t *)&c_crc16x4[0][0])[e];
+		if (tid < 64)
+			((uint32_t *)S.crc8)[tid] = ((const uint32_t *)c_crc8_table)[tid];
+		S.params[tid] = pre_param;
+		if (tid < FA_MAX_ORDER)
+			S.q[tid] = pre_q;
+		stage_store<HIST>(S.u.T, v, bsf, D.wasted, 0);
+	}
+	__syncthreads();
+
+	// ---- what every thread will code, and how long that is ----
+	const uint32_t base = tid * FA_CHUNK;
+	const bool ragged = D.type != FA_SUB_CONSTANT && D.type != FA_SUB_VERBATIM && D.po && (D.psize % FA_CHUNK || D.psize == 0);
+	const bool have = base < bsf && !ragged;
+	uint32_t uz[FA_CHUNK];
+	uint32_t nb = 0, k = 0, warm = 0;
+	bool ps = false;
+	{
+		int32_t d[HIST + FA_CHUNK];
+		if (have)
+			load_chunk_lds<HIST>(d, S.u.T);
+		if (wv == 0 && lane < D.order) {
+			const uint32_t j = HP + lane;
+			warm = (uint32_t)S.u.T[j + (j >> 4)];
+		}
+		if (have && D.type != FA_SUB_CONSTANT) {
+			if (D.type != FA_SUB_VERBATIM) {
+				const uint32_t part = base / D.psize;
+				k = S.params[part];
+				ps = base == part * D.psize;
+			}
+			nb = pq_values_of<HIST, NARROW>(d, D, S.q, base, bsf, k, ps, mode, uz);
+		}
+	}
+	const uint32_t in = sw_scan_incl(nb);
+	if (lane == 63)
+		S.scan[wv] = in;
+	__syncthreads();   // (also: every thread has read what it needs of the staged samples)
+	uint32_t off = 0, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 4; w++) {
+		const uint32_t a = __builtin_amdgcn_readfirstlane(S.scan[w]);
+		off += w < wv ? a : 0u;
+		total += a;
+	}
+	// FLAC__frame_add_header (stream_encoder_framing.c:219); its CRC-8 is one more byte
+	uint64_t hw[2] = {0, 0};
+	uint32_t hn = 0;
+	if (first_piece)
+		hn = frame_header_bytes(P, bsf, B.first_frame + f, ca, hw);
+	const uint32_t front = first_piece ? 8 * (hn + 1) : 0u;
+	uint32_t piece_bits = front + D.hbits + total;
+	// (cannot happen: pack_sub_eligible sized the window for the largest subframe the search can choose, a full block's
+	// partitions are whole chunks and a short block has one, stream_encoder.c:2929; loud if it ever does - the piece is
+	// then written as one empty byte so that the workgroups that wait for it get on)
+	const bool bad = ragged || (piece_bits + 7 + 7 + 16 + 31) / 32 + 3 > PQ_CAPW;
+	if (bad) {
+		piece_bits = front + 8;
+		if (tid == 0)
+			atomicOr(errflag, 1u);
+	}
+	if (tid == 0)
+		__hip_atomic_store(&my_words[0], PS_VALID | piece_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+	// ---- where the piece starts: the pieces in front of it in the frame ----
+	uint32_t before_bits = 0, len_l = 0;   // (wave 0) lane l < c: the length of piece l and the bits in front of it
+	bool placed = false;
+	uint64_t place = 0;
+	uint32_t nbytes = 0;                   // last piece: the frame's bytes without its CRC-16
+	if (wv == 0) {
+		len_l = lane < c ? (ps_wait(&frame_words[2 * lane]) & ~PS_VALID) : 0u;
+		const uint32_t incl = sw_scan_incl(len_l);
+		before_bits = incl - len_l;
+		const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if (lane == 0)
+			S.start_bit = start;
+		if (last_piece) {
+			nbytes = (start + piece_bits + 7) >> 3;   // zero padding to a whole byte (stream_encoder.c:2885)
+			if (lane == 0)
+				__hip_atomic_store(&tickets[f], PQ_SIZE | (uint64_t)(nbytes + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			placed = pq_place<false>(tickets, f, nbytes + 2, lane, place);
+		} else
+			placed = pq_place<false, false>(tickets, f, 0, lane, place);
+	}
+	uint32_t *W = S.u.W;
+	{
+		const uint32_t nw = (piece_bits + 7 + 7 + 16 + 31) / 32 + 3;   // at most PQ_CAPW, see above
+		for (uint32_t i = tid; i < (nw + 3) / 4 && i < PQ_CAPW / 4; i += FA_THREADS)
+			((uint4 *)W)[i] = make_uint4(0, 0, 0, 0);
+	}
+	__syncthreads();
+	const uint32_t start_bit = S.start_bit;
+	const uint32_t r = start_bit & 7u, first_byte = start_bit >> 3;   // window bit 0 is bit 0 of frame byte first_byte
+	const uint32_t pos = r + front;                                   // the subframe's first bit in the window
+
+	// ---- everything into the window ----
+	if (!bad) {
+		if (have && D.type != FA_SUB_CONSTANT)
+			pq_codes(W, D, uz, base, bsf, k, ps, pos + D.hbits + off + (in - nb));
+		// the subframe header (stream_encoder_framing.c:366-479): wave 0 the warm-up samples and the small fields, wave 2 the coefficients
+		const bool predicted = D.type == FA_SUB_FIXED || D.type == FA_SUB_LPC;
+		const uint32_t after_warm = pos + 8 + D.wasted + D.order * D.sbps;
+		if (wv == 0) {
+			if (predicted && lane < D.order)
+				pq_emit(W, pos + 8 + D.wasted + lane * D.sbps, (warm & pq_mask(D.sbps)) << (32u - D.sbps));
+			if (lane == 63) {
+				uint32_t typebits;
+				switch (D.type) {
+				case FA_SUB_CONSTANT: typebits = 0x00; break;
+				case FA_SUB_VERBATIM: typebits = 0x02; break;
+				case FA_SUB_FIXED: typebits = 0x10 | (D.order << 1); break;
+				default: typebits = 0x40 | ((D.order - 1) << 1); break;
+				}
+				pq_emit(W, pos, (typebits | (D.wasted ? 1u : 0u)) << 24);
+				if (D.wasted)
+					pq_emit(W, pos + 8 + D.wasted - 1, 0x80000000u);
+				if (D.type == FA_SUB_CONSTANT)
+					pq_emit(W, pos + 8 + D.wasted, (D.constant & pq_mask(D.sbps)) << (32u - D.sbps));
+				if (D.type == FA_SUB_LPC)
+					pq_emit(W, after_warm, (((D.precision - 1u) << 5) | (D.shift & 31u)) << 23);
+				if (predicted)
+					pq_emit(W, pos + D.hbits - 6, (((D.rice2 ? 1u : 0u) << 4) | D.po) << 26);
+			}
+		} else if (wv == 2 && D.type == FA_SUB_LPC && lane < D.order)
+			pq_emit(W, after_warm + 9 + lane * D.precision, ((uint32_t)S.q[lane] & pq_mask(D.precision)) << (32u - D.precision));
+	}
+	if (first_piece && tid == FA_THREADS - 1) {
+		uint32_t crc = 0;  // FLAC__crc8 (crc.c:124)
+		for (uint32_t i = 0; i < hn; i++)
+			crc = S.crc8[crc ^ hdr_get(hw, i)];
+		hdr_put(hw, hn, crc);
+#pragma unroll
+		for (uint32_t i = 0; i < 4; i++)
+			if (4 * i < hn)
+				pq_emit(W, 32 * i, (uint32_t)(hw[i >> 1] >> ((i & 1u) ? 0 : 32)));   // (the bytes behind the header read as zero)
+	}
+	if (wv == 0 && !placed)
+		placed = last_piece ? pq_place<false>(tickets, f, nbytes + 2, lane, place) : pq_place<false, false>(tickets, f, 0, lane, place);
+	__syncthreads();
+
+	// ---- the CRC-16 of the piece's bytes; the last piece gathers them all (stream_encoder.c:2890-2900) ----
+	const uint32_t end_bit = r + piece_bits;                 // in the window
+	const uint32_t piece_bytes = last_piece ? ((end_bit + 7) >> 3) : ((end_bit + 7) >> 3);
+	const uint32_t own_crc = window_crc16(W, S.crc_tables, S.crcs, piece_bytes);
+	if (!last_piece) {
+		if (tid == 0) {
+			const uint32_t kb = piece_bytes - 1;
+			const uint32_t tail = (end_bit & 7u) ? ((W[kb >> 2] >> (24 - 8 * (kb & 3))) & 0xffu) : 0u;
+			__hip_atomic_store(&my_words[1], PS_VALID | (own_crc << 8) | tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+	if (wv == 0) {
+		// what the pieces in front leave behind: lane l < c, piece l
+		const uint32_t tw = (lane < c && (last_piece || lane == c - 1)) ? ps_wait(&frame_words[2 * lane + 1]) : 0u;
+		if (last_piece) {
+			// piece l covers the frame's bytes [before_bits >> 3, that + ((before_bits & 7) + len_l + 7) >> 3)
+			const uint32_t after = nbytes - (before_bits >> 3) - (((before_bits & 7u) + len_l + 7) >> 3);
+			uint32_t part = lane < c ? gf16_mul((tw >> 8) & 0xffffu, gf16_xpow8(after)) : 0u;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1)
+				part ^= (uint32_t)__shfl_xor((int)part, o, 64);
+			if (lane == 0)
+				pq_emit(W, piece_bytes * 8, (part ^ own_crc) << 16);
+		}
+		if (r && lane == c - 1)
+			atomicOr(&W[0], (tw & 0xffu) << 24);
+		// ---- the frame's place ----
+		if (!placed) {
+			if (last_piece)
+				pq_place<true>(tickets, f, nbytes + 2, lane, place);
+			else
+				pq_place<true, false>(tickets, f, 0, lane, place);
+		}
+		if (lane == 0) {
+			S.place = place;
+			if (last_piece) {
+				offsets[f] = place;
+				if (f == B.nframes - 1)
+					offsets[B.nframes] = place + nbytes + 2;
+				frame_bytes[f] = nbytes + 2;
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- out: the piece's whole bytes (the last piece ends on one, CRC-16 included) ----
+	const uint32_t count = last_piece ? piece_bytes + 2 : end_bit >> 3;
+	const uint64_t at = S.place + first_byte;
+	if (at + count > out_capacity) {
+		if (tid == 0)
+			atomicOr(errflag, 2u);
+		return;
+	}
+	uint8_t *dst = out + at;
+	const uint32_t head = umin32((uint32_t)((16 - ((uintptr_t)dst & 15)) & 15), count);
+	const uint32_t nvec = (count - head) / 16, tail0 = head + 16 * nvec;
+	// byte k of the piece is byte k mod 4, counted from the top, of window word k / 4
+	if (tid < head)
+		dst[tid] = (uint8_t)(W[tid >> 2] >> (24 - 8 * (tid & 3)));
+	if (tid >= FA_THREADS - 16 && tail0 + (tid - (FA_THREADS - 16)) < count) {
+		const uint32_t kk = tail0 + (tid - (FA_THREADS - 16));
+		dst[kk] = (uint8_t)(W[kk >> 2] >> (24 - 8 * (kk & 3)));
+	}
+	const uint32_t sh = head & 3, w0 = head >> 2;
+	for (uint32_t i = tid; i < nvec; i += FA_THREADS) {
+		uint32_t w[5];
+#pragma unroll
+		for (int j = 0; j < 5; j++)
+			w[j] = W[w0 + 4 * i + j];
+		uint4 v;
+		// (a funnel shift by 32 - 8 sh bits; by nothing when the places agree modulo four)
+		v.x = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[0], w[1], 32 - 8 * sh) : w[0]);
+		v.y = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[1], w[2], 32 - 8 * sh) : w[1]);
+		v.z = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[2], w[3], 32 - 8 * sh) : w[2]);
+		v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[3], w[4], 32 - 8 * sh) : w[3]);
+		((uint4 *)(dst + head))[i] = v;
+	}
+}
+
+// Whether k_pack_sub can write this stream's frames.
+static bool pack_sub_eligible(const FaEncParams &P, const FaBatch &B)
+{
+	if (P.blocksize > FA_TILE || P.blocksize % FA_CHUNK || P.channels > 32)
+		return false;
+	uint32_t reach = 0;
+	while (reach < P.max_po && !((P.blocksize >> reach) & 1u))
+		reach++;
+	if ((P.blocksize >> reach) % FA_CHUNK)
+		return false;
+	// The largest subframe: a chosen subframe's estimate never exceeds the verbatim estimate (of a side signal, one bit wider),
+	// and its written size exceeds its estimate by at most half a bit per sample plus one bit per partition; a frame header is
+	// at most 16 bytes.  Behind it the window holds the padding, the CRC-16 and the words a field may reach into.
+	const uint64_t bits = (uint64_t)P.blocksize * (P.bps + 3) + 4096 + 8 * 17 + 64;
+	return (bits + 7 + 7 + 16 + 31) / 32 + 3 <= PQ_CAPW;
+}
+
 // Whether k_pack_frame can write this stream's frames.
 static bool pack_frame_eligible(const FaEncParams &P, const FaBatch &B)
 {
@@ -1259,7 +1620,8 @@ bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 		const char *mode = getenv("FLAC_AMD_PACK");
 		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
 		const uint32_t nfull = B.nframes;   // (a short last block is one partition: it fits too)
-		if (!generic_only && nfull && pack_frame_eligible(P, B)) {
+		// FLAC_AMD_PACK=sub: k_pack_sub also where k_pack_frame would do (for comparisons)
+		if (!generic_only && !(mode && !strcmp(mode, "sub")) && nfull && pack_frame_eligible(P, B)) {
 			const dim3 grid(nfull);
 			// FLAC_AMD_PACK=slots: k_pack_frame into the slots, scan and copy kernels behind it (for comparisons)
 			unsigned long long *tk = (mode && !strcmp(mode, "slots")) ? nullptr : tickets;
@@ -1269,6 +1631,22 @@ bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 			default: hipLaunchKernelGGL(k_pack_frame<32>, grid, block, 0, st, P, B, pcm, stats, plans, assign, slots, frame_bytes, errflag, out, out_capacity, offsets, tk); break;
 			}
 			return tk != nullptr;
+		}
+	}
+	{
+		const char *mode = getenv("FLAC_AMD_PACK");
+		if ((!mode || !strcmp(mode, "sub")) && !stamps && tickets && pack_sub_eligible(P, B)) {
+			const dim3 grid(B.nframes * P.channels);
+			uint32_t *subt = (uint32_t *)(tickets + B.nframes);   // two words per (frame, channel), cleared by k_decide like the tickets
+#define SUB_LAUNCH(H, N) \
+	hipLaunchKernelGGL((k_pack_sub<H, N>), grid, block, 0, st, P, B, pcm, stats, plans, assign, frame_bytes, errflag, out, out_capacity, offsets, tickets, subt)
+			switch (hist) {
+			case 4: SUB_LAUNCH(4, true); break;
+			case 12: if (narrow) SUB_LAUNCH(12, true); else SUB_LAUNCH(12, false); break;
+			default: if (narrow) SUB_LAUNCH(32, true); else SUB_LAUNCH(32, false); break;
+			}
+#undef SUB_LAUNCH
+			return true;
 		}
 	}
 	if (first >= B.nframes)

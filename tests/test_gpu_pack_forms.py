@@ -1,6 +1,8 @@
-"""The frame writer has two forms on the device: k_pack (any stream; a window of the frame's bits that
-slides, one subframe after the other) and k_pack_frame (full blocks of 16-bit stereo with mid/side,
-the benchmark's shape; the whole frame in one window, both subframes in one pass).  Both restate
+"""The frame writer has three forms on the device: k_pack (any stream; a window of the frame's bits that
+slides, one subframe after the other), k_pack_frame (full blocks of 16-bit stereo with mid/side,
+the benchmark's shape; the whole frame in one window, both subframes in one pass) and k_pack_sub (a
+workgroup per written subframe, the pieces meeting at any bit of the output; what every other stream
+with blocks of up to 4096 samples takes).  All restate
 process_frame_'s output (stream_encoder.c:2861: frame header, subframes, padding, CRC-16) for plans the
 model search has made, so they must write the same bytes.  The golden cases pin whichever form their
 shape selects to the reference's bytes; this test holds the two forms against each other on signals and
@@ -37,8 +39,8 @@ SETTINGS = [
 
 def encode(params, pcm, form, first_frame=0):
     import flac_amd
-    if form == "generic":
-        os.environ["FLAC_AMD_PACK"] = "generic"
+    if form in ("generic", "sub"):
+        os.environ["FLAC_AMD_PACK"] = form
     else:
         os.environ.pop("FLAC_AMD_PACK", None)
     try:
@@ -171,3 +173,105 @@ def test_direct_placement_reports_an_output_that_is_too_small():
     pcm = synth.synth_pcm(wide_samples=64 * 4096, sample_rate=44100, channels=2, bits_per_sample=16, seed=5).astype(np.int16)
     with pytest.raises(flac_amd.FlacAmdError):
         _encode_device(p, pcm, 64, 0, capacity=100000)
+
+
+# ---- the subframe form ----
+
+@pytest.mark.parametrize("bs", [4096, 1024, 256])
+def test_subframe_form_writes_what_the_window_form_writes_16_bit_stereo(bs):
+    """The settings and signals of the frame form's test, with every frame cut into its two subframes' workgroups."""
+    import flac_amd
+    sigs = signals(16, 2)
+    for sname, level, over in SETTINGS:
+        p = flac_amd.preset(level, 2, 16, 44100, bs, **over)
+        for name, pcm in sigs.items():
+            pcm = pcm[:bs * 4 + bs // 3]
+            a = encode(p, pcm, "generic")
+            b = encode(p, pcm, "sub")
+            assert len(a) == len(b) == 5
+            for i, (fa, fb) in enumerate(zip(a, b)):
+                assert fa == fb, "%s / %s / blocks of %d: frame %d differs" % (sname, name, bs, i)
+
+
+SHAPES = [(1, 16), (1, 24), (2, 24), (2, 8), (3, 16), (5, 20), (6, 24), (8, 24), (8, 12), (2, 17), (7, 4)]
+
+
+@pytest.mark.parametrize("channels,bps", SHAPES)
+def test_subframe_form_for_every_shape(channels, bps):
+    """One to eight channels, 4 to 24 bits, stereo with and without mid/side: the default writer of these streams against the
+    sliding window, frame by frame (pieces of 8 + bps bits for constant blocks up to whole verbatim subframes, so boundaries at
+    every bit of a byte), and against the CPU restatement of the reference for a level each."""
+    import flac_amd
+    import oracle_lib as O
+    sigs = signals(bps, channels)
+    settings = [("level8", 8, {}), ("level5", 5, {}), ("level0", 0, {}), ("level3", 3, {}),
+                ("level8_po8", 8, {"max_residual_partition_order": 8}), ("level8_p", 8, {"do_qlp_coeff_prec_search": 1})]
+    for bs in (4096, 1152, 192):
+        for sname, level, over in settings:
+            p = flac_amd.preset(level, channels, bps, 48000, bs, **over)
+            for name, pcm in sigs.items():
+                pcm = np.ascontiguousarray(pcm[:bs * 3 + bs // 5])
+                a = encode(p, pcm, "generic")
+                b = encode(p, pcm, None)
+                assert len(a) == len(b) == 4
+                for i, (fa, fb) in enumerate(zip(a, b)):
+                    assert fa == fb, "%s / %s / %d ch %d bits blocks of %d: frame %d differs" % (sname, name, channels, bps, bs, i)
+    p = flac_amd.preset(8, channels, bps, 48000, 4096)
+    op = O.preset(8, channels, bps, 48000, 4096)
+    for name in ("music", "quiet", "wasted"):
+        pcm = np.ascontiguousarray(sigs[name][:4096 * 2 + 77])
+        want, _ = O.encode_frames(op, pcm)
+        assert encode(p, pcm, None) == list(want), name
+
+
+def _encode_device_wide(p, pcm32, nframes, shift, form=None, capacity=None):
+    import torch
+    import flac_amd
+    if form:
+        os.environ["FLAC_AMD_PACK"] = form
+    else:
+        os.environ.pop("FLAC_AMD_PACK", None)
+    try:
+        dev = torch.device("cuda", 0)
+        enc = flac_amd.Encoder(p, device=0, max_frames=nframes)
+        try:
+            cap = enc.max_output_bytes(nframes) if capacity is None else capacity
+            src = torch.from_numpy(pcm32).to(dev)
+            out = torch.full((enc.max_output_bytes(nframes) + 64,), 0xA5, dtype=torch.uint8, device=dev)
+            sizes = torch.zeros(nframes, dtype=torch.int32, device=dev)
+            offs = torch.zeros(nframes + 1, dtype=torch.int64, device=dev)
+            enc.encode_device(src.data_ptr(), 4, pcm32.shape[0], out.data_ptr() + shift, cap, sizes.data_ptr(), offs.data_ptr())
+            torch.cuda.synchronize()
+            enc.status()
+            return out.cpu().numpy(), sizes.cpu().numpy(), offs.cpu().numpy()
+        finally:
+            enc.close()
+    finally:
+        os.environ.pop("FLAC_AMD_PACK", None)
+
+
+@pytest.mark.parametrize("channels,shift", [(8, 0), (8, 5), (3, 1), (2, 3), (1, 2)])
+def test_subframe_form_places_a_long_batch(channels, shift):
+    """More workgroups than the chip holds at once (the waits are for workgroups that started earlier): 700 frames of up to
+    eight channels against the sliding window with its slots, scan and copy; sizes, places, bytes, and nothing outside."""
+    import flac_amd
+    from flac_amd import synth
+    nframes = 700
+    p = flac_amd.preset(8, channels, 24, 96000, 4096)
+    pcm = synth.synth_pcm(wide_samples=nframes * 4096 - 1234, sample_rate=96000, channels=channels, bits_per_sample=24, seed=channels).astype(np.int32)
+    a, sa, oa = _encode_device_wide(p, pcm, nframes, shift, form="generic")
+    b, sb, ob = _encode_device_wide(p, pcm, nframes, shift)
+    assert np.array_equal(sa, sb) and np.array_equal(oa, ob)
+    total = int(ob[nframes])
+    assert total == int(sb.sum())
+    assert np.array_equal(a[shift:shift + total], b[shift:shift + total])
+    assert (b[:shift] == 0xA5).all() and (b[shift + total:] == 0xA5).all()
+
+
+def test_subframe_form_reports_an_output_that_is_too_small():
+    import flac_amd
+    from flac_amd import synth
+    p = flac_amd.preset(8, 6, 24, 96000, 4096)
+    pcm = synth.synth_pcm(wide_samples=64 * 4096, sample_rate=96000, channels=6, bits_per_sample=24, seed=5).astype(np.int32)
+    with pytest.raises(flac_amd.FlacAmdError):
+        _encode_device_wide(p, pcm, 64, 0, capacity=100000)
