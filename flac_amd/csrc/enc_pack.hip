@@ -15,6 +15,9 @@
 
 __constant__ uint16_t c_crc16_table[256];
 __constant__ uint16_t c_crc16_pow[32];  // x^(8 * 2^j) mod the CRC-16 polynomial
+// x^(8 n) for n = i and n = 256 i: two look-ups and one product give any power a frame needs (gf16_xpow8)
+__constant__ uint16_t c_crc16_xp_lo[256];
+__constant__ uint16_t c_crc16_xp_hi[1024];
 __constant__ uint8_t c_crc8_table[256] __attribute__((aligned(16)));
 __constant__ uint16_t c_crc16x4[4][256];    // table k: CRC-16 of a byte followed by k zero bytes
 // window_crc16 works on 256 runs of 1 << c words; thread t's run is followed by 255 - t more
@@ -63,6 +66,16 @@ hipError_t fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, cons
 				r = mul(r, pow16[j]);
 		return r;
 	};
+	static uint16_t xp_lo[256], xp_hi[1024];
+	for (int i = 0; i < 256; i++)
+		xp_lo[i] = (uint16_t)xpow8((uint64_t)i);
+	for (int i = 0; i < 1024; i++)
+		xp_hi[i] = (uint16_t)xpow8(256ull * (uint64_t)i);
+	rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_xp_lo), xp_lo, sizeof(xp_lo));
+	if (rc == hipSuccess)
+		rc = hipMemcpyToSymbol(HIP_SYMBOL(c_crc16_xp_hi), xp_hi, sizeof(xp_hi));
+	if (rc != hipSuccess)
+		return rc;
 	static uint16_t runpow[PK_RUN_CLASSES][FA_THREADS];
 	for (int c = 0; c < PK_RUN_CLASSES; c++)
 		for (int t = 0; t < FA_THREADS; t++)
@@ -86,11 +99,13 @@ __device__ __forceinline__ uint32_t gf16_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
-// x^(8 n) modulo the polynomial
+// x^(8 n) modulo the polynomial.  (Bit by bit over n this was sixteen products in a row, each a hundred dependent
+// instructions of one lane: 20 000 cycles in front of a frame's last bytes.)
 __device__ __forceinline__ uint32_t gf16_xpow8(uint32_t n)
 {
-	uint32_t r = 1;
-	for (int j = 0; n; j++, n >>= 1)
+	uint32_t r = gf16_mul(c_crc16_xp_lo[n & 255u], c_crc16_xp_hi[(n >> 8) & 1023u]);
+	n >>= 18;
+	for (int j = 18; n; j++, n >>= 1)
 		if (n & 1)
 			r = gf16_mul(r, c_crc16_pow[j]);
 	return r;
@@ -924,11 +939,14 @@ __device__ __forceinline__ void pq_codes(uint32_t *W, const PqSub &D, const uint
 // WAIT = false: one look at the 64 tickets in front, no waiting; false if that does not settle it (nothing is published then).
 // PUBLISH = false: only asks where frame f starts (for a workgroup that is not the one that knows the frame's size).
 template <bool WAIT, bool PUBLISH = true>
-__device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f, uint32_t size, uint32_t lane, uint64_t &place)
+__device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f, uint32_t size, uint32_t lane, uint64_t &place, uint32_t *dbg = nullptr)
 {
 	uint64_t before = 0;
 	int64_t at = (int64_t)f - 1;
 	while (at >= 0) {
+#ifdef PS_STAMPS
+		if (dbg) dbg[0]++;
+#endif
 		const int64_t i = at - (int64_t)lane;
 		// (in front of the first frame: a finished sum of nothing)
 		const uint64_t t = i >= 0 ? __hip_atomic_load(&tickets[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : PQ_SUM;
@@ -939,6 +957,9 @@ __device__ __forceinline__ bool pq_place(unsigned long long *tickets, uint32_t f
 		if (is_none & upto) {
 			if (!WAIT)
 				return false;
+#ifdef PS_STAMPS
+			if (dbg) { dbg[1]++; dbg[2] = (uint32_t)__popcll(is_none & upto); }
+#endif
 			__builtin_amdgcn_s_sleep(2);
 			continue;
 		}
@@ -1270,6 +1291,9 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 // out, so the waits end.
 // ---------------------------------------------------------------------------------------------
 #define PS_VALID 0x80000000u
+#ifndef PS_EXP
+#define PS_EXP 0
+#endif
 
 template <int HIST>
 struct PsShared {
@@ -1296,22 +1320,40 @@ __device__ __forceinline__ uint32_t ps_wait(const uint32_t *word)
 	return v;
 }
 
+#ifndef PS_WAVES
+#define PS_WAVES 6   // workgroups per CU (3 / 4 / 5 / 6: 0.67 / 0.55 / 0.49 / 0.45 ms for eight channels of 24 bits: the kernel waits, see below)
+#endif
 template <int HIST, bool NARROW>
-__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PQ_WAVES, PQ_WAVES)))
+__global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PS_WAVES, PS_WAVES)))
 void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaPlan *__restrict__ plans,
                 const uint32_t *__restrict__ assign, uint32_t *__restrict__ frame_bytes, uint32_t *errflag, uint8_t *__restrict__ out,
-                uint64_t out_capacity, uint64_t *__restrict__ offsets, unsigned long long *tickets, uint32_t *subt)
+                uint64_t out_capacity, uint64_t *__restrict__ offsets, unsigned long long *tickets, uint32_t *subt, unsigned long long *stamps)
 {
+// debugging aid (builds with -DPS_STAMPS): thread 0's shader clock at point k goes to stamps[block][k]
+#ifdef PS_STAMPS
+#define PSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64() * 24; } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+	PSTAMP(0);
 	__shared__ PsShared<HIST> S;
 	const uint32_t ch = P.channels;
-	const uint32_t f = blockIdx.x / ch, c = blockIdx.x - f * ch, tid = threadIdx.x, lane = tid & 63u;
+	const uint32_t f = blockIdx.x / ch, tid = threadIdx.x, lane = tid & 63u;
+	// Workgroups go to the chip's eight dies in turn.  Were workgroup j of a frame always channel j, one die would get
+	// every frame's last piece (which waits for all the others) and the rest would wait for that die; so the channels
+	// of a frame are dealt starting one further on each time the deal comes round to the same dies.  (A workgroup may
+	// now wait for one of the up to seven that follow it in its own frame; workgroups still start in order, so those
+	// are never held back by anything but older frames.)
+	const uint32_t low = ch & (0u - ch), period = 8u / (low < 8u ? low : 8u);
+	// (with two channels the pieces in dispatch order are the faster: 0.40 against 0.42 ms for 24-bit stereo)
+	const uint32_t c = ch <= 2 ? blockIdx.x - f * ch : (blockIdx.x - f * ch + f / period) % ch;
 	const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const bool first_piece = c == 0, last_piece = c == ch - 1;
 	const uint32_t bsf = frame_len(B, P.blocksize, f);
 	const uint64_t frame_start = (uint64_t)f * P.blocksize;
 	constexpr uint32_t HP = ST_HP(HIST);
 	constexpr uint32_t NIT = (HP + FA_TILE + FA_THREADS - 1) / FA_THREADS;
-	uint32_t *my_words = subt + 2 * (size_t)blockIdx.x;
+	uint32_t *my_words = subt + 2 * ((size_t)f * ch + c);
 	const uint32_t *frame_words = subt + 2 * (size_t)f * ch;
 
 	// ---- which signal this subframe is (stream_encoder.c:3091-3151), and everything it needs from memory ----
@@ -1359,9 +1401,11 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		S.params[tid] = pre_param;
 		if (tid < FA_MAX_ORDER)
 			S.q[tid] = pre_q;
+		PSTAMP(1);
 		stage_store<HIST>(S.u.T, v, bsf, D.wasted, 0);
 	}
 	__syncthreads();
+	PSTAMP(2);
 
 	// ---- what every thread will code, and how long that is ----
 	const uint32_t base = tid * FA_CHUNK;
@@ -1384,13 +1428,22 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 				k = S.params[part];
 				ps = base == part * D.psize;
 			}
+#if PS_EXP == 4
+			nb = 100 + (d[HIST] & 15);
+#pragma unroll
+			for (int i = 0; i < FA_CHUNK; i++)
+				uz[i] = (uint32_t)d[HIST + i] & 31u;
+#else
 			nb = pq_values_of<HIST, NARROW>(d, D, S.q, base, bsf, k, ps, mode, uz);
+#endif
 		}
 	}
 	const uint32_t in = sw_scan_incl(nb);
+	PSTAMP(3);
 	if (lane == 63)
 		S.scan[wv] = in;
 	__syncthreads();   // (also: every thread has read what it needs of the staged samples)
+	PSTAMP(4);
 	uint32_t off = 0, total = 0;
 #pragma unroll
 	for (uint32_t w = 0; w < 4; w++) {
@@ -1418,40 +1471,47 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		__hip_atomic_store(&my_words[0], PS_VALID | piece_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 	// ---- where the piece starts: the pieces in front of it in the frame ----
-	uint32_t before_bits = 0, len_l = 0;   // (wave 0) lane l < c: the length of piece l and the bits in front of it
-	bool placed = false;
+	// A workgroup's time is mostly round trips to other workgroups' words, so they are taken side by side: wave 0 talks to
+	// the frame's other pieces, wave 1 to the tickets of the frames in front (and, in the last piece, adds up the frame as
+	// well, rather than wait for wave 0 to tell it).
+	uint32_t before_bits = 0, len_l = 0;   // (waves 0 and 1) lane l < c: the length of piece l and the bits in front of it
+	bool placed = false;                   // (wave 1)
 	uint64_t place = 0;
 	uint32_t nbytes = 0;                   // last piece: the frame's bytes without its CRC-16
-	if (wv == 0) {
+	if (wv == 0 || (wv == 1 && last_piece)) {
 		len_l = lane < c ? (ps_wait(&frame_words[2 * lane]) & ~PS_VALID) : 0u;
 		const uint32_t incl = sw_scan_incl(len_l);
 		before_bits = incl - len_l;
 		const uint32_t start = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		if (lane == 0)
+		if (wv == 0 && lane == 0)
 			S.start_bit = start;
 		if (last_piece) {
 			nbytes = (start + piece_bits + 7) >> 3;   // zero padding to a whole byte (stream_encoder.c:2885)
-			if (lane == 0)
+			if (wv == 1 && lane == 0)
 				__hip_atomic_store(&tickets[f], PQ_SIZE | (uint64_t)(nbytes + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			placed = pq_place<false>(tickets, f, nbytes + 2, lane, place);
-		} else
-			placed = pq_place<false, false>(tickets, f, 0, lane, place);
+		}
 	}
+	if (wv == 1)
+		placed = last_piece ? pq_place<false>(tickets, f, nbytes + 2, lane, place) : pq_place<false, false>(tickets, f, 0, lane, place);
 	uint32_t *W = S.u.W;
 	{
 		const uint32_t nw = (piece_bits + 7 + 7 + 16 + 31) / 32 + 3;   // at most PQ_CAPW, see above
 		for (uint32_t i = tid; i < (nw + 3) / 4 && i < PQ_CAPW / 4; i += FA_THREADS)
 			((uint4 *)W)[i] = make_uint4(0, 0, 0, 0);
 	}
+	PSTAMP(5);
 	__syncthreads();
+	PSTAMP(6);
 	const uint32_t start_bit = S.start_bit;
 	const uint32_t r = start_bit & 7u, first_byte = start_bit >> 3;   // window bit 0 is bit 0 of frame byte first_byte
 	const uint32_t pos = r + front;                                   // the subframe's first bit in the window
 
 	// ---- everything into the window ----
 	if (!bad) {
+#if PS_EXP != 1
 		if (have && D.type != FA_SUB_CONSTANT)
 			pq_codes(W, D, uz, base, bsf, k, ps, pos + D.hbits + off + (in - nb));
+#endif
 		// the subframe header (stream_encoder_framing.c:366-479): wave 0 the warm-up samples and the small fields, wave 2 the coefficients
 		const bool predicted = D.type == FA_SUB_FIXED || D.type == FA_SUB_LPC;
 		const uint32_t after_warm = pos + 8 + D.wasted + D.order * D.sbps;
@@ -1489,14 +1549,21 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 			if (4 * i < hn)
 				pq_emit(W, 32 * i, (uint32_t)(hw[i >> 1] >> ((i & 1u) ? 0 : 32)));   // (the bytes behind the header read as zero)
 	}
-	if (wv == 0 && !placed)
+	if (wv == 1 && !placed)
 		placed = last_piece ? pq_place<false>(tickets, f, nbytes + 2, lane, place) : pq_place<false, false>(tickets, f, 0, lane, place);
+	PSTAMP(7);
 	__syncthreads();
+	PSTAMP(8);
 
 	// ---- the CRC-16 of the piece's bytes; the last piece gathers them all (stream_encoder.c:2890-2900) ----
 	const uint32_t end_bit = r + piece_bits;                 // in the window
 	const uint32_t piece_bytes = last_piece ? ((end_bit + 7) >> 3) : ((end_bit + 7) >> 3);
+#if PS_EXP == 3
+	const uint32_t own_crc = 0;
+#else
 	const uint32_t own_crc = window_crc16(W, S.crc_tables, S.crcs, piece_bytes);
+#endif
+	PSTAMP(9);
 	if (!last_piece) {
 		if (tid == 0) {
 			const uint32_t kb = piece_bytes - 1;
@@ -1519,13 +1586,27 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		}
 		if (r && lane == c - 1)
 			atomicOr(&W[0], (tw & 0xffu) << 24);
+	} else if (wv == 1) {
 		// ---- the frame's place ----
+#ifdef PS_STAMPS
+		if (stamps && lane == 0) {
+			stamps[(size_t)blockIdx.x * 16 + 13] = wall_clock64() * 24;
+			stamps[(size_t)blockIdx.x * 16 + 15] = placed ? 1 : 0;
+		}
+#endif
+		uint32_t dbg[3] = {0, 0, 0};
 		if (!placed) {
 			if (last_piece)
-				pq_place<true>(tickets, f, nbytes + 2, lane, place);
+				pq_place<true>(tickets, f, nbytes + 2, lane, place, dbg);
 			else
-				pq_place<true, false>(tickets, f, 0, lane, place);
+				pq_place<true, false>(tickets, f, 0, lane, place, dbg);
 		}
+#ifdef PS_STAMPS
+		if (stamps && lane == 0) {
+			stamps[(size_t)blockIdx.x * 16 + 14] = wall_clock64() * 24;
+			stamps[(size_t)blockIdx.x * 16 + 15] = (placed ? 1 : 0) | ((uint64_t)dbg[0] << 8) | ((uint64_t)dbg[1] << 24) | ((uint64_t)dbg[2] << 48);
+		}
+#endif
 		if (lane == 0) {
 			S.place = place;
 			if (last_piece) {
@@ -1536,7 +1617,9 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 			}
 		}
 	}
+	PSTAMP(10);
 	__syncthreads();
+	PSTAMP(11);
 
 	// ---- out: the piece's whole bytes (the last piece ends on one, CRC-16 included) ----
 	const uint32_t count = last_piece ? piece_bytes + 2 : end_bit >> 3;
@@ -1547,6 +1630,10 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		return;
 	}
 	uint8_t *dst = out + at;
+#if PS_EXP == 2
+	if (count > 64)
+		return;
+#endif
 	const uint32_t head = umin32((uint32_t)((16 - ((uintptr_t)dst & 15)) & 15), count);
 	const uint32_t nvec = (count - head) / 16, tail0 = head + 16 * nvec;
 	// byte k of the piece is byte k mod 4, counted from the top, of window word k / 4
@@ -1570,6 +1657,8 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(w[3], w[4], 32 - 8 * sh) : w[3]);
 		((uint4 *)(dst + head))[i] = v;
 	}
+	PSTAMP(12);
+#undef PSTAMP
 }
 
 // Whether k_pack_sub can write this stream's frames.
@@ -1618,7 +1707,11 @@ bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 	uint32_t first = 0;
 	{
 		const char *mode = getenv("FLAC_AMD_PACK");
+#ifdef PS_STAMPS
+		const bool generic_only = mode && !strcmp(mode, "generic");
+#else
 		const bool generic_only = (mode && !strcmp(mode, "generic")) || stamps;
+#endif
 		const uint32_t nfull = B.nframes;   // (a short last block is one partition: it fits too)
 		// FLAC_AMD_PACK=sub: k_pack_sub also where k_pack_frame would do (for comparisons)
 		if (!generic_only && !(mode && !strcmp(mode, "sub")) && nfull && pack_frame_eligible(P, B)) {
@@ -1635,11 +1728,16 @@ bool fa_launch_pack(const FaEncParams &P, const FaBatch &B, const void *pcm, con
 	}
 	{
 		const char *mode = getenv("FLAC_AMD_PACK");
-		if ((!mode || !strcmp(mode, "sub")) && !stamps && tickets && pack_sub_eligible(P, B)) {
+#ifdef PS_STAMPS
+		const bool sub_ok = true;
+#else
+		const bool sub_ok = !stamps;
+#endif
+		if ((!mode || !strcmp(mode, "sub")) && sub_ok && tickets && pack_sub_eligible(P, B)) {
 			const dim3 grid(B.nframes * P.channels);
 			uint32_t *subt = (uint32_t *)(tickets + B.nframes);   // two words per (frame, channel), cleared by k_decide like the tickets
 #define SUB_LAUNCH(H, N) \
-	hipLaunchKernelGGL((k_pack_sub<H, N>), grid, block, 0, st, P, B, pcm, stats, plans, assign, frame_bytes, errflag, out, out_capacity, offsets, tickets, subt)
+	hipLaunchKernelGGL((k_pack_sub<H, N>), grid, block, 0, st, P, B, pcm, stats, plans, assign, frame_bytes, errflag, out, out_capacity, offsets, tickets, subt, stamps)
 			switch (hist) {
 			case 4: SUB_LAUNCH(4, true); break;
 			case 12: if (narrow) SUB_LAUNCH(12, true); else SUB_LAUNCH(12, false); break;
