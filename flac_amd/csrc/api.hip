@@ -90,6 +90,7 @@ struct flacamd_encoder {
 	uint64_t *offsets;
 	uint32_t *errflag;    // [0] device error bits, [1] loose mid/side state out
 	int32_t *planes;      // streams of three or more channels: the batch's samples as 32-bit planes per frame (k_planes)
+	void *stat_acc;       // where the tiles of a block add up its statistics when the planes' pass makes them too
 	// staging for the host-buffer entry point
 	int32_t *stage_pcm;
 	int16_t *stage_host16;  // pinned: samples narrowed to 16 bits before they cross PCIe
@@ -177,6 +178,7 @@ extern "C" void flacamd_encoder_destroy(flacamd_encoder *e)
 	(void)hipFree(e->assign);
 	(void)hipFree(e->slots);
 	(void)hipFree(e->planes);
+	(void)hipFree(e->stat_acc);
 	(void)hipFree(e->frame_bytes);
 	(void)hipFree(e->offsets);
 	(void)hipFree(e->errflag);
@@ -243,6 +245,8 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 		const bool on = env ? (atoi(env) != 0 && p.channels >= 2) : p.channels >= 3;
 		if (on)
 			ALLOC(e->planes, sizeof(int32_t) * F * p.channels * p.blocksize);
+		if (on && fa_planes_stats_fit(P))
+			ALLOC(e->stat_acc, fa_stat_acc_bytes((uint32_t)F, p.channels));
 	}
 	ALLOC(e->frame_bytes, sizeof(uint32_t) * F);
 	ALLOC(e->offsets, sizeof(uint64_t) * (F + 1));
@@ -317,6 +321,7 @@ extern "C" int flacamd_encoder_stage_ms(flacamd_encoder *e, float ms[FLACAMD_ENC
 // The device buffers one batch works in, whoever owns them.
 struct EncWork {
 	int32_t *planes;      // null: the kernels read the caller's samples as they lie
+	void *stat_acc;       // not null: the planes' pass also makes the statistics
 	const float *windows;
 	FaSubStat *stats;
 	float *autoc;
@@ -371,13 +376,21 @@ static int run_batch(const FaEncParams &P, const FaBatch &Bin, const EncWork &W,
 	} while (0)
 	const char *stamps_env = getenv("FLAC_AMD_STAMPS");
 	STAGE_MARK();
+	bool have_stats = false;
 	if (W.planes && !B.pairs) {
-		fa_launch_planes(P, B, pcm_in, W.planes, st);
+		// FLAC_AMD_ANALYZE=split: the planes and the statistics in two passes (for comparisons)
+		const char *am = getenv("FLAC_AMD_ANALYZE");
+		if (W.stat_acc && !(am && !strcmp(am, "split"))) {
+			fa_launch_planes_stats(P, B, pcm_in, W.planes, W.stat_acc, W.stats, st);
+			have_stats = true;
+		} else
+			fa_launch_planes(P, B, pcm_in, W.planes, st);
 		B.planar = P.blocksize;
 		B.sample_bytes = 4;
 		pcm_dev = W.planes;
 	}
-	fa_launch_analyze(P, B, pcm_dev, W.stats, st);
+	if (!have_stats)
+		fa_launch_analyze(P, B, pcm_dev, W.stats, st);
 	STAGE_MARK();
 	if (P.max_lpc_order > 0)
 		fa_launch_autoc(P, B, pcm_dev, W.stats, W.windows, W.autoc, st);
@@ -430,6 +443,7 @@ extern "C" int flacamd_encode_frames(flacamd_encoder *e, const void *pcm_dev, ui
 	hipStream_t st = (hipStream_t)stream;
 	EncWork W;
 	W.planes = e->planes;
+	W.stat_acc = e->stat_acc;
 	W.windows = e->windows;
 	W.stats = e->stats;
 	W.autoc = e->autoc;
@@ -671,6 +685,7 @@ extern "C" int flacamd_encode_frames_static(const flacamd_encode_params *pin, in
 	}
 	EncWork W;
 	W.planes = nullptr;   // (planes of a whole batch would not fit the static buffer)
+	W.stat_acc = nullptr;
 	W.windows = (const float *)(base + L.windows);
 	W.stats = (FaSubStat *)(base + L.stats);
 	W.autoc = (float *)(base + L.autoc);

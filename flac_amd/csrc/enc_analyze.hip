@@ -44,6 +44,184 @@ __global__ __launch_bounds__(256) void k_planes(FaEncParams P, FaBatch B, const 
 			planes[((size_t)f * ch + c) * P.blocksize + t0 + tid] = t[c * 257 + tid];
 }
 
+// What the statistics passes leave per (frame, signal), from the sums of the fixed predictors' absolute errors over the
+// signal with its wasted bits gone (fixed.c:264-282: the order guess and the bits per sample each order would cost).
+__device__ __forceinline__ FaSubStat make_stat(const FaEncParams &P, uint32_t bsf, uint32_t wasted, uint32_t extra_bit, int32_t first, uint32_t ne,
+                                               const uint64_t (&sums)[5])
+{
+	FaSubStat st;
+	st.wasted = wasted;
+	st.bps = P.bps - wasted + extra_bit;
+	st.first_sample = first >> wasted;
+	st.is_constant = 0;
+	st.fixed_guess = 0;
+	for (int k = 0; k < 5; k++)
+		st.rbps[k] = 0.0f;
+	if (bsf >= 4) {
+		uint64_t t[5];
+		for (int k = 0; k < 5; k++)
+			t[k] = P.wide_fixed ? sums[k] : (sums[k] & 0xffffffffull);  // uint32 accumulators wrap (fixed.c:234)
+		auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
+		uint32_t order;
+		if (t[0] < mn(mn(mn(t[1], t[2]), t[3]), t[4])) order = 0;
+		else if (t[1] < mn(mn(t[2], t[3]), t[4])) order = 1;
+		else if (t[2] < mn(t[3], t[4])) order = 2;
+		else if (t[3] < t[4]) order = 3;
+		else order = 4;
+		st.fixed_guess = order;
+		const double n = (double)(bsf - 4);
+		for (int k = 0; k < 5; k++)
+			st.rbps[k] = (float)(t[k] > 0 ? log(M_LN2 * (double)t[k] / n) / M_LN2 : 0.0);
+		st.is_constant = (!P.disable_constant && st.rbps[1] == 0.0f && ne == 0) ? 1u : 0u;
+	}
+	return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_planes_stats + k_stats_finish: k_planes and k_analyze in one pass over the samples, for streams of three or more
+// channels of up to 24 bits.  A workgroup takes PS_TILE wide samples of a frame: reads them along memory, turns them
+// in LDS, writes each channel's run into its plane, and a thread per (channel, sixteen samples) adds up what the
+// statistics need of them: the OR of the samples, whether any differs from the channel's first, and the five error
+// sums, taken over the samples AS THEY ARE.  The wasted bits are only known once the whole block has been seen, but
+// every difference of samples that all end in w zero bits ends in w zero bits, so the sums over the shifted samples
+// are the sums over the unshifted ones shifted by w: k_stats_finish, a lane per (frame, channel), does that and the
+// rest.  The tiles of a block meet in 64-bit atomic adds (`acc`, cleared beforehand).
+// ---------------------------------------------------------------------------------------------
+#define PS_TILE 512
+#define PS_HP 16                                 // rows in front of the tile (the predictors need four)
+#define PS_ROWW (((PS_TILE + PS_HP) / 16) * 17)   // words of a channel's row in LDS: sixteen samples to seventeen words
+struct FaStatAcc {
+	unsigned long long sums[5];
+	uint32_t orv, ne;
+	int32_t first;
+	uint32_t pad;
+};
+
+__global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, const void *pcm, int32_t *planes, FaStatAcc *acc, uint32_t tiles)
+{
+	__shared__ int32_t x[FLACAMD_MAX_CHANNELS * PS_ROWW];
+	const uint32_t f = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * PS_TILE, tid = threadIdx.x;
+	const uint32_t bsf = frame_len(B, P.blocksize, f), ch = P.channels;
+	if (t0 >= bsf)
+		return;
+	const uint32_t n = umin32((uint32_t)PS_TILE, bsf - t0);        // samples of the tile
+	const uint32_t lead = t0 ? (uint32_t)PS_HP : 0u;               // rows in front of it that exist
+	const uint64_t first_el = ((uint64_t)f * P.blocksize + t0 - lead) * ch;
+	const uint32_t nel = (n + lead) * ch;
+	constexpr uint32_t NIT = ((PS_TILE + PS_HP) * FLACAMD_MAX_CHANNELS + 255) / 256;
+	// every load first; local row j = PS_HP + (sample - t0)
+	int32_t v[NIT];
+#pragma unroll
+	for (uint32_t k = 0; k < NIT; k++) {
+		const uint32_t e = tid + 256 * k;
+		v[k] = e < nel ? read_pcm(pcm, B.sample_bytes, first_el + e) : 0;
+	}
+	// the channel's first sample of the block (for the all-samples-equal test)
+	const uint32_t item = tid, ic = item >> 5, chunk = item & 31u;   // thread -> (channel, sixteen samples); ch * 32 of them at most
+	const bool worker = ic < ch;
+	const int32_t first = worker ? read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + ic) : 0;
+#pragma unroll
+	for (uint32_t k = 0; k < NIT; k++) {
+		const uint32_t e = tid + 256 * k;
+		if (e < nel) {
+			const uint32_t i = e / ch, c = e - i * ch, j = i + (PS_HP - lead);
+			x[c * PS_ROWW + j + (j >> 4)] = v[k];
+		}
+	}
+	__syncthreads();
+	// the planes
+	for (uint32_t c = 0; c < ch; c++) {
+		int32_t *dst = planes + ((size_t)f * ch + c) * P.blocksize + t0;
+		for (uint32_t i = tid; i < n; i += 256) {
+			const uint32_t j = i + PS_HP;
+			dst[i] = x[c * PS_ROWW + j + (j >> 4)];
+		}
+	}
+	// the statistics: channels 8 r .. 8 r + 7 in round r (one round unless there are more than eight channels)
+	for (uint32_t c = ic; c < ch; c += 8) {
+		const uint32_t base = t0 + 16 * chunk;   // the thread's first sample, counted in the block
+		uint32_t orv = 0, ne = 0;
+		uint64_t te[5] = {0, 0, 0, 0, 0};
+		if (base < bsf) {
+			int32_t d[4 + 16];
+			const int32_t *row = x + c * PS_ROWW + (chunk + PS_HP / 16) * 17;
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				d[k] = row[-17 + 12 + k];          // the last four samples of the sixteen before
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				d[4 + k] = row[k];
+			const int32_t fs = c == ic ? first : read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + c);
+			const uint32_t BIAS = 0x80000000u;
+			uint32_t t32[5] = {0, 0, 0, 0, 0};
+			uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+			for (int k = 0; k < 4 + 16; k++) {
+				const uint32_t b0 = (uint32_t)d[k] ^ BIAS;
+				const uint32_t b1 = (b0 - p0) ^ BIAS, b2 = (b1 - p1) ^ BIAS, b3 = (b2 - p2) ^ BIAS;
+				if (k >= 4) {
+					const uint32_t idx = base + (uint32_t)(k - 4);
+					if (idx < bsf) {
+						orv |= (uint32_t)d[k];
+						ne |= (uint32_t)(d[k] != fs);
+					}
+					if (idx >= 4 && idx < bsf) {
+						t32[0] = sad_u32(b0, BIAS, t32[0]);
+						t32[1] = sad_u32(b0, p0, t32[1]);
+						t32[2] = sad_u32(b1, p1, t32[2]);
+						t32[3] = sad_u32(b2, p2, t32[3]);
+						t32[4] = sad_u32(b3, p3, t32[4]);
+					}
+					if ((k & 3) == 3) {
+						// (four errors of up to 28 bits: no carry out of 32)
+						te[0] += t32[0]; te[1] += t32[1]; te[2] += t32[2]; te[3] += t32[3]; te[4] += t32[4];
+						t32[0] = t32[1] = t32[2] = t32[3] = t32[4] = 0;
+					}
+				}
+				p0 = b0;
+				p1 = b1;
+				p2 = b2;
+				p3 = b3;
+			}
+		}
+		// the 32 threads of a channel are half a wave
+#pragma unroll
+		for (int o = 16; o > 0; o >>= 1) {
+			orv |= (uint32_t)__shfl_xor((int)orv, o, 64);
+			ne |= (uint32_t)__shfl_xor((int)ne, o, 64);
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				te[k] += __shfl_xor(te[k], o, 64);
+		}
+		if (chunk == 0) {
+			FaStatAcc *a = acc + (size_t)f * ch + c;
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				if (te[k])
+					atomicAdd(&a->sums[k], (unsigned long long)te[k]);
+			if (orv)
+				atomicOr(&a->orv, orv);
+			if (ne)
+				atomicOr(&a->ne, 1u);
+			if (t0 == 0)
+				a->first = x[c * PS_ROWW + PS_HP + (PS_HP >> 4)];
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_stats_finish(FaEncParams P, FaBatch B, const FaStatAcc *acc, FaSubStat *stats)
+{
+	const uint32_t task = blockIdx.x * 256 + threadIdx.x;
+	if (task >= B.nframes * P.channels)
+		return;
+	const FaStatAcc a = acc[task];
+	const uint32_t wasted = a.orv ? (uint32_t)__ffs((int)a.orv) - 1u : 0u;
+	uint64_t t[5];
+	for (int k = 0; k < 5; k++)
+		t[k] = a.sums[k] >> wasted;
+	stats[task] = make_stat(P, frame_len(B, P.blocksize, task / P.channels), wasted, 0u, a.first, a.ne, t);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_analyze: get_wasted_bits_ (stream_encoder.c:4108) + FLAC__fixed_compute_best_predictor[_wide]
 // (fixed.c:224,282) + the all-samples-equal test of process_subframe_ (:3210-3227)
@@ -195,35 +373,10 @@ __global__ __launch_bounds__(FA_THREADS) void k_analyze(FaEncParams P, FaBatch B
 			sh_te[tid >> 6][k] = te[k];
 	__syncthreads();
 	if (tid == 0) {
-		FaSubStat st;
-		st.wasted = wasted;
-		st.bps = P.bps - wasted + ((P.do_ms && s == P.channels + 1) ? 1u : 0u);
-		st.first_sample = first >> wasted;
-		st.is_constant = 0;
-		st.fixed_guess = 0;
+		uint64_t t[5];
 		for (int k = 0; k < 5; k++)
-			st.rbps[k] = 0.0f;
-		if (bsf >= 4) {
-			uint64_t t[5];
-			for (int k = 0; k < 5; k++) {
-				t[k] = sh_te[0][k] + sh_te[1][k] + sh_te[2][k] + sh_te[3][k];
-				if (!P.wide_fixed)
-					t[k] &= 0xffffffffull;  // uint32 accumulators wrap (fixed.c:234)
-			}
-			auto mn = [](uint64_t a, uint64_t b) { return a < b ? a : b; };
-			uint32_t order;
-			if (t[0] < mn(mn(mn(t[1], t[2]), t[3]), t[4])) order = 0;
-			else if (t[1] < mn(mn(t[2], t[3]), t[4])) order = 1;
-			else if (t[2] < mn(t[3], t[4])) order = 2;
-			else if (t[3] < t[4]) order = 3;
-			else order = 4;
-			st.fixed_guess = order;
-			const double n = (double)(bsf - 4);
-			for (int k = 0; k < 5; k++)
-				st.rbps[k] = (float)(t[k] > 0 ? log(M_LN2 * (double)t[k] / n) / M_LN2 : 0.0);
-			st.is_constant = (!P.disable_constant && st.rbps[1] == 0.0f && ne == 0) ? 1u : 0u;
-		}
-		stats[task] = st;
+			t[k] = sh_te[0][k] + sh_te[1][k] + sh_te[2][k] + sh_te[3][k];
+		stats[task] = make_stat(P, bsf, wasted, (P.do_ms && s == P.channels + 1) ? 1u : 0u, first, ne, t);
 	}
 }
 
@@ -1036,6 +1189,19 @@ void fa_launch_planes(const FaEncParams &P, const FaBatch &B, const void *pcm, i
 {
 	const uint32_t tiles = (P.blocksize + 255) / 256;
 	hipLaunchKernelGGL(k_planes, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, tiles);
+}
+
+size_t fa_stat_acc_bytes(uint32_t nframes, uint32_t channels) { return sizeof(FaStatAcc) * (size_t)nframes * channels; }
+
+// Whether the planes and the statistics can be made in one pass (then fa_launch_analyze is not needed).
+bool fa_planes_stats_fit(const FaEncParams &P) { return P.bps <= 24 && P.nsignals == P.channels && P.channels <= 8; }
+
+void fa_launch_planes_stats(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, void *acc, FaSubStat *stats, hipStream_t st)
+{
+	const uint32_t tiles = (P.blocksize + PS_TILE - 1) / PS_TILE;
+	(void)hipMemsetAsync(acc, 0, fa_stat_acc_bytes(B.nframes, P.channels), st);
+	hipLaunchKernelGGL(k_planes_stats, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles);
+	hipLaunchKernelGGL(k_stats_finish, dim3((B.nframes * P.channels + 255) / 256), dim3(256), 0, st, P, B, (const FaStatAcc *)acc, stats);
 }
 
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st)
