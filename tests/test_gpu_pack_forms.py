@@ -275,3 +275,40 @@ def test_subframe_form_reports_an_output_that_is_too_small():
     pcm = synth.synth_pcm(wide_samples=64 * 4096, sample_rate=96000, channels=6, bits_per_sample=24, seed=5).astype(np.int32)
     with pytest.raises(flac_amd.FlacAmdError):
         _encode_device_wide(p, pcm, 64, 0, capacity=100000)
+
+
+@pytest.mark.parametrize("channels,bps,bs", [(8, 24, 16384), (8, 24, 4608), (6, 24, 8192), (8, 16, 65535), (2, 24, 32768), (5, 20, 10000)])
+def test_window_form_for_frames_of_many_windows(channels, bps, bs):
+    """Blocks beyond 4096 samples stay with the sliding window, and with many channels a frame is many windows long (up to 1.5 MB):
+    against the CPU restatement of the reference on signals whose subframes begin at every distance from a window's end (the fields
+    in front of a subframe's codes are written once and need room in the window)."""
+    import flac_amd
+    import oracle_lib as O
+    rng = np.random.default_rng(bs + channels)
+    full = 1 << (bps - 1)
+    n = bs * 2 + 999
+    t = np.arange(n, dtype=np.float64)
+    music = np.stack([0.5 * np.sin(2 * np.pi * (0.003 + 0.0017 * c) * t + c) + 0.1 * np.sin(2 * np.pi * 0.041 * t) for c in range(channels)], axis=1)
+    sigs = {
+        "music": (music * full * 0.9 + rng.normal(0, full / 300.0, size=(n, channels))),
+        "loud": (music * full * 0.5 + rng.normal(0, full / 8.0, size=(n, channels))),
+        "noise": rng.integers(-full, full, size=(n, channels)).astype(np.float64),
+    }
+    for level in (8, 5):
+        p = flac_amd.preset(level, channels, bps, 96000, bs)
+        op = O.preset(level, channels, bps, 96000, bs)
+        for name, x in sigs.items():
+            pcm = np.ascontiguousarray(np.clip(x, -full, full - 1).astype(np.int32))
+            want, _ = O.encode_frames(op, pcm)
+            # Full-scale noise in blocks of 65 535: the reference's 32-bit sums of residual magnitudes wrap (stream_encoder.c:3704), it
+            # picks Rice parameters far too small and writes frames of 1.5 MB where verbatim would be 1.0 MB.  The device reserves what a
+            # frame can take when its estimate holds, and says so when a frame does not fit - a limit, not a silent difference.
+            verbatim = channels * ((bs * bps + 7) // 8 + 2) + 32
+            if max(len(w) for w in want) > verbatim + bs * channels // 8:
+                with pytest.raises(flac_amd.FlacAmdError):
+                    encode(p, pcm, None)
+                continue
+            got = encode(p, pcm, None)
+            assert len(got) == len(want) == 3
+            for i in range(3):
+                assert got[i] == bytes(want[i]), "%s level %d: frame %d differs" % (name, level, i)
