@@ -245,8 +245,8 @@ extern "C" int flacamd_encoder_create(const flacamd_encode_params *pin, int devi
 		const bool on = env ? (atoi(env) != 0 && p.channels >= 2) : p.channels >= 3;
 		if (on)
 			ALLOC(e->planes, sizeof(int32_t) * F * p.channels * p.blocksize);
-		if (on && fa_planes_stats_fit(P))
-			ALLOC(e->stat_acc, fa_stat_acc_bytes((uint32_t)F, p.channels));
+		if (fa_planes_stats_fit(P))
+			ALLOC(e->stat_acc, fa_stat_acc_bytes((uint32_t)F, P.nsignals));
 	}
 	ALLOC(e->frame_bytes, sizeof(uint32_t) * F);
 	ALLOC(e->offsets, sizeof(uint64_t) * (F + 1));
@@ -377,10 +377,11 @@ static int run_batch(const FaEncParams &P, const FaBatch &Bin, const EncWork &W,
 	const char *stamps_env = getenv("FLAC_AMD_STAMPS");
 	STAGE_MARK();
 	bool have_stats = false;
+	// FLAC_AMD_ANALYZE=split: the planes and the statistics in two passes, k_analyze for every stream but 16-bit stereo (for comparisons)
+	const char *am = getenv("FLAC_AMD_ANALYZE");
+	const bool one_pass = W.stat_acc && !(am && !strcmp(am, "split"));
 	if (W.planes && !B.pairs) {
-		// FLAC_AMD_ANALYZE=split: the planes and the statistics in two passes (for comparisons)
-		const char *am = getenv("FLAC_AMD_ANALYZE");
-		if (W.stat_acc && !(am && !strcmp(am, "split"))) {
+		if (one_pass) {
 			fa_launch_planes_stats(P, B, pcm_in, W.planes, W.stat_acc, W.stats, st);
 			have_stats = true;
 		} else
@@ -388,6 +389,11 @@ static int run_batch(const FaEncParams &P, const FaBatch &Bin, const EncWork &W,
 		B.planar = P.blocksize;
 		B.sample_bytes = 4;
 		pcm_dev = W.planes;
+	}
+	else if (one_pass && !(B.pairs && P.nsignals == 4 && !P.wide_fixed)) {
+		// (16-bit stereo with mid/side keeps k_analyze_quad: one word per wide sample, sums of 32 bits)
+		fa_launch_planes_stats(P, B, pcm_in, nullptr, W.stat_acc, W.stats, st);
+		have_stats = true;
 	}
 	if (!have_stats)
 		fa_launch_analyze(P, B, pcm_dev, W.stats, st);

@@ -78,9 +78,10 @@ __device__ __forceinline__ FaSubStat make_stat(const FaEncParams &P, uint32_t bs
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_planes_stats + k_stats_finish: k_planes and k_analyze in one pass over the samples, for streams of three or more
-// channels of up to 24 bits.  A workgroup takes PS_TILE wide samples of a frame: reads them along memory, turns them
-// in LDS, writes each channel's run into its plane, and a thread per (channel, sixteen samples) adds up what the
+// k_planes_stats + k_stats_finish: k_planes and k_analyze in one pass over the samples, for streams of up to eight
+// channels of up to 24 bits (with mid and side when there are two; without the planes when the stream is read as it
+// lies).  A workgroup takes PS_TILE wide samples of a frame: reads them along memory, turns them
+// in LDS, writes each channel's run into its plane, and a thread per (signal, sixteen samples) adds up what the
 // statistics need of them: the OR of the samples, whether any differs from the channel's first, and the five error
 // sums, taken over the samples AS THEY ARE.  The wasted bits are only known once the whole block has been seen, but
 // every difference of samples that all end in w zero bits ends in w zero bits, so the sums over the shifted samples
@@ -116,10 +117,17 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 		const uint32_t e = tid + 256 * k;
 		v[k] = e < nel ? read_pcm(pcm, B.sample_bytes, first_el + e) : 0;
 	}
-	// the channel's first sample of the block (for the all-samples-equal test)
-	const uint32_t item = tid, ic = item >> 5, chunk = item & 31u;   // thread -> (channel, sixteen samples); ch * 32 of them at most
-	const bool worker = ic < ch;
-	const int32_t first = worker ? read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + ic) : 0;
+	// thread -> (signal, sixteen samples); a signal is a channel, or mid / side of the first two (stream_encoder.c:1991-1992)
+	const uint32_t sg = tid >> 5, chunk = tid & 31u;
+	const bool worker = sg < P.nsignals;
+	const uint32_t kind = sg < ch ? 0u : (sg == ch ? 1u : 2u), ca = kind ? 0u : sg, cb = kind ? 1u : sg;
+	// the signal's first sample of the block (for the all-samples-equal test)
+	int32_t first = 0;
+	if (worker) {
+		const int32_t fa = read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + ca);
+		const int32_t fb = kind ? read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + cb) : fa;
+		first = sig_combine(kind, fa, fb);
+	}
 #pragma unroll
 	for (uint32_t k = 0; k < NIT; k++) {
 		const uint32_t e = tid + 256 * k;
@@ -130,28 +138,28 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 	}
 	__syncthreads();
 	// the planes
-	for (uint32_t c = 0; c < ch; c++) {
+	for (uint32_t c = 0; planes && c < ch; c++) {
 		int32_t *dst = planes + ((size_t)f * ch + c) * P.blocksize + t0;
 		for (uint32_t i = tid; i < n; i += 256) {
 			const uint32_t j = i + PS_HP;
 			dst[i] = x[c * PS_ROWW + j + (j >> 4)];
 		}
 	}
-	// the statistics: channels 8 r .. 8 r + 7 in round r (one round unless there are more than eight channels)
-	for (uint32_t c = ic; c < ch; c += 8) {
+	// the statistics
+	if (worker) {
 		const uint32_t base = t0 + 16 * chunk;   // the thread's first sample, counted in the block
 		uint32_t orv = 0, ne = 0;
 		uint64_t te[5] = {0, 0, 0, 0, 0};
 		if (base < bsf) {
 			int32_t d[4 + 16];
-			const int32_t *row = x + c * PS_ROWW + (chunk + PS_HP / 16) * 17;
+			const int32_t *rowa = x + ca * PS_ROWW + (chunk + PS_HP / 16) * 17, *rowb = x + cb * PS_ROWW + (chunk + PS_HP / 16) * 17;
 #pragma unroll
 			for (int k = 0; k < 4; k++)
-				d[k] = row[-17 + 12 + k];          // the last four samples of the sixteen before
+				d[k] = sig_combine(kind, rowa[-17 + 12 + k], rowb[-17 + 12 + k]);          // the last four samples of the sixteen before
 #pragma unroll
 			for (int k = 0; k < 16; k++)
-				d[4 + k] = row[k];
-			const int32_t fs = c == ic ? first : read_pcm(pcm, B.sample_bytes, (uint64_t)f * P.blocksize * ch + c);
+				d[4 + k] = sig_combine(kind, rowa[k], rowb[k]);
+			const int32_t fs = first;
 			const uint32_t BIAS = 0x80000000u;
 			uint32_t t32[5] = {0, 0, 0, 0, 0};
 			uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 						t32[4] = sad_u32(b3, p3, t32[4]);
 					}
 					if ((k & 3) == 3) {
-						// (four errors of up to 28 bits: no carry out of 32)
+						// (four errors of up to 29 bits - a side signal of 25, differenced four times: no carry out of 32)
 						te[0] += t32[0]; te[1] += t32[1]; te[2] += t32[2]; te[3] += t32[3]; te[4] += t32[4];
 						t32[0] = t32[1] = t32[2] = t32[3] = t32[4] = 0;
 					}
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 				te[k] += __shfl_xor(te[k], o, 64);
 		}
 		if (chunk == 0) {
-			FaStatAcc *a = acc + (size_t)f * ch + c;
+			FaStatAcc *a = acc + (size_t)f * P.nsignals + sg;
 #pragma unroll
 			for (int k = 0; k < 5; k++)
 				if (te[k])
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 			if (ne)
 				atomicOr(&a->ne, 1u);
 			if (t0 == 0)
-				a->first = x[c * PS_ROWW + PS_HP + (PS_HP >> 4)];
+				a->first = first;
 		}
 	}
 }
@@ -212,14 +220,15 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 __global__ __launch_bounds__(256) void k_stats_finish(FaEncParams P, FaBatch B, const FaStatAcc *acc, FaSubStat *stats)
 {
 	const uint32_t task = blockIdx.x * 256 + threadIdx.x;
-	if (task >= B.nframes * P.channels)
+	if (task >= B.nframes * P.nsignals)
 		return;
 	const FaStatAcc a = acc[task];
 	const uint32_t wasted = a.orv ? (uint32_t)__ffs((int)a.orv) - 1u : 0u;
 	uint64_t t[5];
 	for (int k = 0; k < 5; k++)
 		t[k] = a.sums[k] >> wasted;
-	stats[task] = make_stat(P, frame_len(B, P.blocksize, task / P.channels), wasted, 0u, a.first, a.ne, t);
+	const uint32_t f = task / P.nsignals, sg = task - f * P.nsignals;
+	stats[task] = make_stat(P, frame_len(B, P.blocksize, f), wasted, (P.do_ms && sg == P.channels + 1) ? 1u : 0u, a.first, a.ne, t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1191,17 +1200,21 @@ void fa_launch_planes(const FaEncParams &P, const FaBatch &B, const void *pcm, i
 	hipLaunchKernelGGL(k_planes, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, tiles);
 }
 
-size_t fa_stat_acc_bytes(uint32_t nframes, uint32_t channels) { return sizeof(FaStatAcc) * (size_t)nframes * channels; }
+size_t fa_stat_acc_bytes(uint32_t nframes, uint32_t nsignals) { return sizeof(FaStatAcc) * (size_t)nframes * nsignals; }
 
-// Whether the planes and the statistics can be made in one pass (then fa_launch_analyze is not needed).
-bool fa_planes_stats_fit(const FaEncParams &P) { return P.bps <= 24 && P.nsignals == P.channels && P.channels <= 8; }
+// Whether k_planes_stats can make this stream's statistics (then fa_launch_analyze is not needed).
+bool fa_planes_stats_fit(const FaEncParams &P)
+{
+	return P.bps <= 24 && P.channels <= 8 && (P.nsignals == P.channels || (P.channels == 2 && P.nsignals == 4));
+}
 
+// planes: null = the statistics alone (the kernels behind read the samples as they lie)
 void fa_launch_planes_stats(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, void *acc, FaSubStat *stats, hipStream_t st)
 {
 	const uint32_t tiles = (P.blocksize + PS_TILE - 1) / PS_TILE;
-	(void)hipMemsetAsync(acc, 0, fa_stat_acc_bytes(B.nframes, P.channels), st);
+	(void)hipMemsetAsync(acc, 0, fa_stat_acc_bytes(B.nframes, P.nsignals), st);
 	hipLaunchKernelGGL(k_planes_stats, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles);
-	hipLaunchKernelGGL(k_stats_finish, dim3((B.nframes * P.channels + 255) / 256), dim3(256), 0, st, P, B, (const FaStatAcc *)acc, stats);
+	hipLaunchKernelGGL(k_stats_finish, dim3((B.nframes * P.nsignals + 255) / 256), dim3(256), 0, st, P, B, (const FaStatAcc *)acc, stats);
 }
 
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st)

@@ -667,9 +667,9 @@ __device__ __forceinline__ int lpc_mode(uint32_t wide, uint32_t sbps) { return w
 // bps + precision + ilog2(order) <= 32 (stream_encoder.c:3592) holds for the largest values possible.
 static inline bool fa_narrow_only(const FaEncParams &P)
 {
-	if (P.max_lpc_order == 0)
-		return true;
 	const uint32_t max_sbps = P.bps + (P.do_ms ? 1u : 0u);
+	if (P.max_lpc_order == 0)
+		return max_sbps <= 24;   // (the fixed predictors' taps are 24-bit multiplies too: a side signal of 25 bits is not for them)
 	const uint32_t max_prec = P.prec_search ? 15u : P.qlp_precision;
 	uint32_t lg = 0;
 	while ((2u << lg) <= P.max_lpc_order)
@@ -680,7 +680,7 @@ static inline bool fa_narrow_only(const FaEncParams &P)
 static inline int fa_hist_class(const FaEncParams &P)
 {
 	if (P.max_lpc_order == 0)
-		return 4;
+		return fa_narrow_only(P) ? 4 : 12;   // (the four-sample history class is compiled for narrow streams only)
 	return P.max_lpc_order <= 12 ? 12 : 32;
 }
 

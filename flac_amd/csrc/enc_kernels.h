@@ -9,8 +9,8 @@
 hipError_t fa_upload_crc_tables(const uint16_t *t16, const uint16_t *pow16, const uint8_t *t8);
 // interleaved samples of any width -> 32-bit planes [frame][channel][blocksize]
 void fa_launch_planes(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, hipStream_t st);
-// planes and statistics in one pass (streams that fa_planes_stats_fit): acc is scratch of fa_stat_acc_bytes
-size_t fa_stat_acc_bytes(uint32_t nframes, uint32_t channels);
+// planes (or none: null) and statistics in one pass (streams that fa_planes_stats_fit): acc is scratch of fa_stat_acc_bytes
+size_t fa_stat_acc_bytes(uint32_t nframes, uint32_t nsignals);
 bool fa_planes_stats_fit(const FaEncParams &P);
 void fa_launch_planes_stats(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, void *acc, FaSubStat *stats, hipStream_t st);
 void fa_launch_analyze(const FaEncParams &P, const FaBatch &B, const void *pcm, FaSubStat *stats, hipStream_t st);

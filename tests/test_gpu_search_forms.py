@@ -119,3 +119,24 @@ def test_both_forms_against_the_oracle_on_other_shapes(bps, channels):
             want, _ = O.encode_frames(op, pcm)
             for form in ("generic", "wave"):
                 assert encode(p, pcm, form) == list(want), (sname, name, bps, channels, form)
+
+
+def test_fixed_predictors_on_a_side_signal_of_25_bits():
+    """-l 0 on 24-bit stereo with mid/side, blocks beyond 4096 (the workgroup form of the search): a side signal that uses its 25th
+    bit (full-scale channels in opposite phase) is not for 24-bit multiplies; against the CPU restatement of the reference."""
+    import flac_amd
+    import oracle_lib as O
+    sigs = signals(24, 2)
+    for bs in (16384, 8192):
+        for level in (2, 1):
+            p = flac_amd.preset(level, 2, 24, 48000, bs)
+            op = O.preset(level, 2, 24, 48000, bs)
+            for name in ("square", "noise", "music"):
+                pcm = np.ascontiguousarray(sigs[name])
+                want, _ = O.encode_frames(op, pcm)
+                enc = flac_amd.Encoder(p, device=0, max_frames=8)
+                try:
+                    got, _ = enc.encode_host(pcm)
+                finally:
+                    enc.close()
+                assert got == [bytes(w) for w in want], (bs, level, name)
