@@ -88,9 +88,10 @@ __device__ __forceinline__ FaSubStat make_stat(const FaEncParams &P, uint32_t bs
 // are the sums over the unshifted ones shifted by w: k_stats_finish, a lane per (frame, channel), does that and the
 // rest.  The tiles of a block meet in 64-bit atomic adds (`acc`, cleared beforehand).
 // ---------------------------------------------------------------------------------------------
-#define PS_TILE 512
+// CPS: threads per signal (each takes sixteen samples), so a tile is 16 * CPS wide samples: 32 for up to eight
+// signals, 64 / 128 / 256 for up to four / two / one - always 256 threads' worth.
 #define PS_HP 16                                 // rows in front of the tile (the predictors need four)
-#define PS_ROWW (((PS_TILE + PS_HP) / 16) * 17)   // words of a channel's row in LDS: sixteen samples to seventeen words
+#define PS_ROWW(TILE) ((((TILE) + PS_HP) / 16) * 17)   // words of a channel's row in LDS: sixteen samples to seventeen words
 struct FaStatAcc {
 	unsigned long long sums[5];
 	uint32_t orv, ne;
@@ -98,9 +99,12 @@ struct FaStatAcc {
 	uint32_t pad;
 };
 
+template <int CPS>
 __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, const void *pcm, int32_t *planes, FaStatAcc *acc, uint32_t tiles)
 {
-	__shared__ int32_t x[FLACAMD_MAX_CHANNELS * PS_ROWW];
+	constexpr uint32_t PS_TILE = 16 * CPS, ROWW = PS_ROWW(PS_TILE);
+	constexpr uint32_t MAXCH = CPS == 32 ? FLACAMD_MAX_CHANNELS : CPS == 64 ? 4 : CPS == 128 ? 2 : 1;   // channels <= signals <= 256 / CPS
+	__shared__ int32_t x[MAXCH * ROWW];
 	const uint32_t f = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * PS_TILE, tid = threadIdx.x;
 	const uint32_t bsf = frame_len(B, P.blocksize, f), ch = P.channels;
 	if (t0 >= bsf)
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 	const uint32_t lead = t0 ? (uint32_t)PS_HP : 0u;               // rows in front of it that exist
 	const uint64_t first_el = ((uint64_t)f * P.blocksize + t0 - lead) * ch;
 	const uint32_t nel = (n + lead) * ch;
-	constexpr uint32_t NIT = ((PS_TILE + PS_HP) * FLACAMD_MAX_CHANNELS + 255) / 256;
+	constexpr uint32_t NIT = ((PS_TILE + PS_HP) * MAXCH + 255) / 256;
 	// every load first; local row j = PS_HP + (sample - t0)
 	int32_t v[NIT];
 #pragma unroll
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 		v[k] = e < nel ? read_pcm(pcm, B.sample_bytes, first_el + e) : 0;
 	}
 	// thread -> (signal, sixteen samples); a signal is a channel, or mid / side of the first two (stream_encoder.c:1991-1992)
-	const uint32_t sg = tid >> 5, chunk = tid & 31u;
+	const uint32_t sg = tid / CPS, chunk = tid % CPS;
 	const bool worker = sg < P.nsignals;
 	const uint32_t kind = sg < ch ? 0u : (sg == ch ? 1u : 2u), ca = kind ? 0u : sg, cb = kind ? 1u : sg;
 	// the signal's first sample of the block (for the all-samples-equal test)
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 		const uint32_t e = tid + 256 * k;
 		if (e < nel) {
 			const uint32_t i = e / ch, c = e - i * ch, j = i + (PS_HP - lead);
-			x[c * PS_ROWW + j + (j >> 4)] = v[k];
+			x[c * ROWW + j + (j >> 4)] = v[k];
 		}
 	}
 	__syncthreads();
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 		int32_t *dst = planes + ((size_t)f * ch + c) * P.blocksize + t0;
 		for (uint32_t i = tid; i < n; i += 256) {
 			const uint32_t j = i + PS_HP;
-			dst[i] = x[c * PS_ROWW + j + (j >> 4)];
+			dst[i] = x[c * ROWW + j + (j >> 4)];
 		}
 	}
 	// the statistics
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 		uint64_t te[5] = {0, 0, 0, 0, 0};
 		if (base < bsf) {
 			int32_t d[4 + 16];
-			const int32_t *rowa = x + ca * PS_ROWW + (chunk + PS_HP / 16) * 17, *rowb = x + cb * PS_ROWW + (chunk + PS_HP / 16) * 17;
+			const int32_t *rowa = x + ca * ROWW + (chunk + PS_HP / 16) * 17, *rowb = x + cb * ROWW + (chunk + PS_HP / 16) * 17;
 #pragma unroll
 			for (int k = 0; k < 4; k++)
 				d[k] = sig_combine(kind, rowa[-17 + 12 + k], rowb[-17 + 12 + k]);          // the last four samples of the sixteen before
@@ -192,16 +196,16 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 				p3 = b3;
 			}
 		}
-		// the 32 threads of a channel are half a wave
+		// the threads of a signal are half a wave, or whole waves
 #pragma unroll
-		for (int o = 16; o > 0; o >>= 1) {
+		for (int o = (CPS < 64 ? CPS : 64) / 2; o > 0; o >>= 1) {
 			orv |= (uint32_t)__shfl_xor((int)orv, o, 64);
 			ne |= (uint32_t)__shfl_xor((int)ne, o, 64);
 #pragma unroll
 			for (int k = 0; k < 5; k++)
 				te[k] += __shfl_xor(te[k], o, 64);
 		}
-		if (chunk == 0) {
+		if ((chunk & 63u) == 0) {
 			FaStatAcc *a = acc + (size_t)f * P.nsignals + sg;
 #pragma unroll
 			for (int k = 0; k < 5; k++)
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k_planes_stats(FaEncParams P, FaBatch B, 
 				atomicOr(&a->orv, orv);
 			if (ne)
 				atomicOr(&a->ne, 1u);
-			if (t0 == 0)
+			if (t0 == 0 && chunk == 0)
 				a->first = first;
 		}
 	}
@@ -1211,9 +1215,16 @@ bool fa_planes_stats_fit(const FaEncParams &P)
 // planes: null = the statistics alone (the kernels behind read the samples as they lie)
 void fa_launch_planes_stats(const FaEncParams &P, const FaBatch &B, const void *pcm, int32_t *planes, void *acc, FaSubStat *stats, hipStream_t st)
 {
-	const uint32_t tiles = (P.blocksize + PS_TILE - 1) / PS_TILE;
+	const uint32_t cps = P.nsignals > 4 ? 32u : P.nsignals > 2 ? 64u : P.nsignals > 1 ? 128u : 256u;
+	const uint32_t tiles = (P.blocksize + 16 * cps - 1) / (16 * cps);
+	const dim3 grid(B.nframes * tiles);
 	(void)hipMemsetAsync(acc, 0, fa_stat_acc_bytes(B.nframes, P.nsignals), st);
-	hipLaunchKernelGGL(k_planes_stats, dim3(B.nframes * tiles), dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles);
+	switch (cps) {
+	case 32: hipLaunchKernelGGL(k_planes_stats<32>, grid, dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles); break;
+	case 64: hipLaunchKernelGGL(k_planes_stats<64>, grid, dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles); break;
+	case 128: hipLaunchKernelGGL(k_planes_stats<128>, grid, dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles); break;
+	default: hipLaunchKernelGGL(k_planes_stats<256>, grid, dim3(256), 0, st, P, B, pcm, planes, (FaStatAcc *)acc, tiles); break;
+	}
 	hipLaunchKernelGGL(k_stats_finish, dim3((B.nframes * P.nsignals + 255) / 256), dim3(256), 0, st, P, B, (const FaStatAcc *)acc, stats);
 }
 
