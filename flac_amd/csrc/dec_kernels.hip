@@ -220,7 +220,9 @@ __device__ bool parse_frame_header(const uint8_t *d, uint64_t p, const FaDecPara
 // lived for one load: 1.4 TB/s; four blocks: the 46 MB of the bench stream in 38 -> 20 us).
 // The headers found are also kept as parsed, the first SYNC_KEEP of a block in the order the threads come by (`kept`,
 // SYNC_KEEP rows per block): the emitting pass then has nothing to read again and parse, only to put them in order.
+#ifndef SYNC_SUB
 #define SYNC_SUB 4
+#endif
 #define SYNC_KEEP 8
 __global__ __launch_bounds__(SYNC_THREADS) void k_dec_sync(FaDecParams P, const uint8_t *d, const FaStream *streams, uint32_t *block_counts, uint32_t nb,
                                                            FaFrameCand *kept)

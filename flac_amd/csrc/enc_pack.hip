@@ -1291,9 +1291,6 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 // out, so the waits end.
 // ---------------------------------------------------------------------------------------------
 #define PS_VALID 0x80000000u
-#ifndef PS_EXP
-#define PS_EXP 0
-#endif
 
 template <int HIST>
 struct PsShared {
@@ -1428,14 +1425,7 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 				k = S.params[part];
 				ps = base == part * D.psize;
 			}
-#if PS_EXP == 4
-			nb = 100 + (d[HIST] & 15);
-#pragma unroll
-			for (int i = 0; i < FA_CHUNK; i++)
-				uz[i] = (uint32_t)d[HIST + i] & 31u;
-#else
 			nb = pq_values_of<HIST, NARROW>(d, D, S.q, base, bsf, k, ps, mode, uz);
-#endif
 		}
 	}
 	const uint32_t in = sw_scan_incl(nb);
@@ -1508,10 +1498,8 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 
 	// ---- everything into the window ----
 	if (!bad) {
-#if PS_EXP != 1
 		if (have && D.type != FA_SUB_CONSTANT)
 			pq_codes(W, D, uz, base, bsf, k, ps, pos + D.hbits + off + (in - nb));
-#endif
 		// the subframe header (stream_encoder_framing.c:366-479): wave 0 the warm-up samples and the small fields, wave 2 the coefficients
 		const bool predicted = D.type == FA_SUB_FIXED || D.type == FA_SUB_LPC;
 		const uint32_t after_warm = pos + 8 + D.wasted + D.order * D.sbps;
@@ -1557,12 +1545,8 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 
 	// ---- the CRC-16 of the piece's bytes; the last piece gathers them all (stream_encoder.c:2890-2900) ----
 	const uint32_t end_bit = r + piece_bits;                 // in the window
-	const uint32_t piece_bytes = last_piece ? ((end_bit + 7) >> 3) : ((end_bit + 7) >> 3);
-#if PS_EXP == 3
-	const uint32_t own_crc = 0;
-#else
+	const uint32_t piece_bytes = (end_bit + 7) >> 3;
 	const uint32_t own_crc = window_crc16(W, S.crc_tables, S.crcs, piece_bytes);
-#endif
 	PSTAMP(9);
 	if (!last_piece) {
 		if (tid == 0) {
@@ -1630,10 +1614,6 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 		return;
 	}
 	uint8_t *dst = out + at;
-#if PS_EXP == 2
-	if (count > 64)
-		return;
-#endif
 	const uint32_t head = umin32((uint32_t)((16 - ((uintptr_t)dst & 15)) & 15), count);
 	const uint32_t nvec = (count - head) / 16, tail0 = head + 16 * nvec;
 	// byte k of the piece is byte k mod 4, counted from the top, of window word k / 4

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/scratch/ab_cfg.sh <config> <lib.so>...: encode kernel times of bench.py --config for the default build and each variant
+# tools/ab_configs.sh <config> <lib.so>...: encode kernel times of bench.py --config for the default build and each variant
 cfg=$1; shift
 mkdir -p gpurun_out/ab
 run() {

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Phase timeline of k_pack_sub workgroups (a workgroup per written subframe) from in-kernel time stamps.
+Needs a build of enc_pack.hip with -DPS_STAMPS (tools/build_variant.sh psstamps enc_pack.hip -DPS_STAMPS) selected through
+FLAC_AMD_LIB; the stamps are the 100 MHz wall clock scaled to shader cycles, so that they compare across the chip's dies.
+usage: FLAC_AMD_LIB=$PWD/flac_amd/lib/exp/psstamps.so python tools/stamps_pack_sub.py [C4|C3]"""
 import os, sys
 os.environ["FLAC_AMD_STAMPS"] = "pack"
 sys.path.insert(0, ".")
