@@ -1354,7 +1354,8 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
 	const uint32_t *frame_words = subt + 2 * (size_t)f * ch;
 
 	// ---- which signal this subframe is (stream_encoder.c:3091-3151), and everything it needs from memory ----
-	const uint32_t ca = __builtin_amdgcn_readfirstlane(assign[f]);
+	// (without mid/side nothing else waits for this load: the assignment is "independent" then, stream_encoder.c:3091)
+	const uint32_t ca = P.do_ms ? __builtin_amdgcn_readfirstlane(assign[f]) : 0u;
 	uint32_t sig = c;
 	if (ca == 1 && c == 1) sig = ch + 1;       // left, side
 	else if (ca == 2 && c == 0) sig = ch + 1;  // side, right
