@@ -669,6 +669,44 @@ __global__ __launch_bounds__(256) void k_dec_output(FaDecParams P, const FaStrea
 					((int2 *)lds)[(fl * row + ii * 2) >> 1] = make_int2(a, b);
 			}
 		}
+	} else if (ch > 2 && ch <= 8 && LW >= 4 && !planar) {
+		// more channels, the same way: four frames' values of one sample are 16 bytes of every plane; a frame's values of the
+		// sample leave for LDS together
+		for (uint32_t idx = tid * 4; idx < tile_samples * LW; idx += 256 * 4) {
+			const uint32_t fl0 = idx & (LW - 1), ii = idx >> lw_log;
+			const uint32_t i = i0 + ii;
+			if (i >= P.max_blocksize)
+				continue;
+			int32_t v[8][4];
+#pragma unroll
+			for (uint32_t c = 0; c < 8; c++) {
+				int4 t = make_int4(0, 0, 0, 0);
+				if (c < ch)
+					t = *(const int4 *)(frame_tmp + ((size_t)c * P.max_blocksize + i) * LW + fl0);
+				v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t fl = fl0 + j;
+				if (!(sc[fl].status == 1 && !(sc[fl].reserved & 2u) && i < sc[fl].blocksize))
+					continue;
+				const uint32_t at = fl * row + ii * ch;
+				if (sb == 4 && (ch & 3u) == 0) {
+					((int4 *)lds)[at >> 2] = make_int4(v[0][j], v[1][j], v[2][j], v[3][j]);
+					if (ch == 8)
+						((int4 *)lds)[(at >> 2) + 1] = make_int4(v[4][j], v[5][j], v[6][j], v[7][j]);
+				} else {
+#pragma unroll
+					for (uint32_t c = 0; c < 8; c++)
+						if (c < ch) {
+							if (sb == 2)
+								((int16_t *)lds)[at + c] = (int16_t)v[c][j];
+							else
+								((int32_t *)lds)[at + c] = v[c][j];
+						}
+				}
+			}
+		}
 	} else
 	for (uint32_t idx = tid; idx < tile_samples * LW; idx += 256) {
 		const uint32_t fl = idx & (LW - 1), ii = idx >> lw_log;

@@ -388,3 +388,25 @@ def test_subframe_records_match_a_parse_of_the_subframe_headers():
                     assert rec.params[0] == p0
             checked += 1
     assert checked >= 40
+
+
+@pytest.mark.parametrize("channels", [1, 3, 4, 5, 6, 7, 8])
+def test_every_channel_count_and_output_width_comes_back(channels):
+    """The pass that turns the decoded planes into interleaved samples takes four frames' values of a sample at a time for
+    three to eight channels (whole vectors where the channel count and the output width allow, single values otherwise):
+    streams of every channel count, 12 / 16 / 24 bits, into 16- and 32-bit output, with a short last block and block sizes that
+    are not a multiple of anything, against the samples that went in."""
+    import flac_amd
+    for bps, bs, level in ((16, 4096, 5), (24, 1152, 8), (12, 999, 3)):
+        nframes = 37
+        pcm, frames = _synthetic_stream(channels, bps, 48000, bs, level, nframes, 100 * channels + bps)
+        n = pcm.shape[0]
+        blob = b"".join(frames)
+        dec = flac_amd.Decoder(channels, bps, bs, device=0, max_input_bytes=len(blob) + 64, max_frames=nframes + 8)
+        try:
+            for osb in ((2, 4) if bps <= 16 else (4,)):
+                out, nfr, wide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=osb)
+                assert nfr == nframes and wide == n and bad == 0
+                assert np.array_equal(np.asarray(out, dtype=np.int32), pcm), (channels, bps, bs, osb)
+        finally:
+            dec.close()
