@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void k(uint64_t *stamps, uint32_t *out, int blo
 }
 
 template <int V>
-void run(const char *name, int waves, uint32_t lanes)
+void run(const char *name, int waves, uint32_t lanes, uint32_t kp1 = 7u)
 {
 	uint64_t *stamps;
 	uint32_t *out;
@@ -86,13 +86,13 @@ void run(const char *name, int waves, uint32_t lanes)
 	hipMalloc(&out, sizeof(uint32_t) * 64 * waves);
 	const int blocks = 256;
 	for (int rep = 0; rep < 3; rep++)
-		hipLaunchKernelGGL(k<V>, dim3(waves), dim3(64), 0, 0, stamps, out, blocks, lanes, 7u);
+		hipLaunchKernelGGL(k<V>, dim3(waves), dim3(64), 0, 0, stamps, out, blocks, lanes, kp1);
 	hipDeviceSynchronize();
 	std::vector<uint64_t> h(waves);
 	hipMemcpy(h.data(), stamps, sizeof(uint64_t) * waves, hipMemcpyDeviceToHost);
 	std::sort(h.begin(), h.end());
 	const double per = (double)h[waves / 2] / (blocks * 16.0) / (V == 3 ? 2.0 : 1.0);
-	printf("%-44s waves %5d lanes %2u  cycles per symbol (median wave) %.1f\n", name, waves, lanes, per);
+	printf("%-44s waves %5d lanes %2u  k+1 %2u  cycles per symbol (median wave) %.1f\n", name, waves, lanes, kp1, per);
 	hipFree(stamps);
 	hipFree(out);
 }
@@ -105,5 +105,8 @@ int main()
 		run<2>("2 ring word requested before the step", waves, 8);
 		run<3>("3 two streams per lane, interleaved", waves, 8);
 	}
+	// symbols of 24-bit streams are twice as long: a step into the next word every other symbol
+	for (uint32_t kp1 : {7u, 11u, 15u, 19u})
+		run<0>("0 ring word requested after the step", 352, 8, kp1);
 	return 0;
 }
