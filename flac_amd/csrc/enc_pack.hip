@@ -1287,8 +1287,8 @@ void k_pack_frame(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const 
 //     (multiplication by a power of x) and XORs them.
 // The frame's place in the output comes from the tickets as in k_pack_frame: the last channel's
 // workgroup, which knows the frame's size, publishes it and later the running sum; the others only
-// ask.  Every wait is for a workgroup with a smaller index, and nobody waits before its length is
-// out, so the waits end.
+// ask.  Every wait is for a workgroup of an older frame or of the same frame, workgroups start in
+// order, and nobody waits before its length is out, so the waits end.
 // ---------------------------------------------------------------------------------------------
 #define PS_VALID 0x80000000u
 
@@ -1306,7 +1306,6 @@ struct PsShared {
 	int32_t q[FA_MAX_ORDER];
 	uint64_t place;
 	uint32_t start_bit;   // of the piece, counted from the frame's first bit
-	uint32_t placed;
 };
 
 __device__ __forceinline__ uint32_t ps_wait(const uint32_t *word)
@@ -1326,7 +1325,8 @@ void k_pack_sub(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const Fa
                 const uint32_t *__restrict__ assign, uint32_t *__restrict__ frame_bytes, uint32_t *errflag, uint8_t *__restrict__ out,
                 uint64_t out_capacity, uint64_t *__restrict__ offsets, unsigned long long *tickets, uint32_t *subt, unsigned long long *stamps)
 {
-// debugging aid (builds with -DPS_STAMPS): thread 0's shader clock at point k goes to stamps[block][k]
+// debugging aid (builds with -DPS_STAMPS): thread 0's time at point k goes to stamps[block][k] (the 100 MHz wall clock, which all
+// dies share, scaled to shader cycles)
 #ifdef PS_STAMPS
 #define PSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64() * 24; } while (0)
 #else
