@@ -360,7 +360,10 @@ struct SwCand {
 #define SW_WAVES 4   // waves per SIMD: 128 registers each
 #endif
 template <int RES, bool PAIRS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES == SW_SPLIT ? 2 : SW_WAVES, RES == SW_SPLIT ? 2 : SW_WAVES)))
+#ifndef SW_SPLIT_WAVES
+#define SW_SPLIT_WAVES 2   // the split form: 229 registers (at three waves 168 and 324 bytes of scratch per lane: 0.75 -> 0.93 ms for eight channels of 24 bits)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RES == SW_SPLIT ? SW_SPLIT_WAVES : SW_WAVES, RES == SW_SPLIT ? SW_SPLIT_WAVES : SW_WAVES)))
 void k_search_wave(FaEncParams P, FaBatch B, const void *__restrict__ pcm, const FaSubStat *__restrict__ stats, const FaLpcCand *__restrict__ cands,
                    const int32_t *__restrict__ coefs, FaPlan *__restrict__ plans, unsigned long long sig_list, uint32_t nsel)
 {
