@@ -1317,7 +1317,7 @@ __device__ __forceinline__ uint32_t ps_wait(const uint32_t *word)
 }
 
 #ifndef PS_WAVES
-#define PS_WAVES 6   // workgroups per CU (3 / 4 / 5 / 6: 0.67 / 0.55 / 0.49 / 0.45 ms for eight channels of 24 bits: the kernel waits, see below)
+#define PS_WAVES 6   // workgroups per CU (3 / 4 / 5 / 6: 0.67 / 0.55 / 0.49 / 0.45 ms for eight channels of 24 bits: the kernel waits, see below; with a smaller window seven or eight fit, and spill: 0.31 -> 0.36 / 0.45)
 #endif
 template <int HIST, bool NARROW>
 __global__ __launch_bounds__(FA_THREADS) __attribute__((amdgpu_waves_per_eu(PS_WAVES, PS_WAVES)))
