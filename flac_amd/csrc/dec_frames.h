@@ -735,14 +735,7 @@ __device__ __forceinline__ void pipe_cut_symbols(PX &X, uint32_t hand, uint32_t 
 // The four sit in the four banks of a row of sixteen lanes (lane = 16 r + 4 t + i for subframe 4 r + i), so that
 // "the next thread" is a shift by four lanes and "not the first" is a bank mask.  The samples stay as they are in LDS
 // ([sample][lane], the instance's stride); the wasted bits are shifted back in on the way out.
-// SPLIT: some lane's sum needs 64 bits (FLAC__lpc_restore_signal_wide, lpc.c:1061), every sample fits 24 bits and no order is above
-// sixteen.  A sample is s = sh 2^12 + sl with sl its low twelve bits, so the sum is A 2^12 + B with A = sum q sh and B = sum q sl, both
-// inside 32 bits (coefficients of up to 15 bits, sixteen taps: below 2^30), both chains of 24-bit multiply-adds; and
-// floor((A 2^12 + B) / 2^shift) is (A + (B >> 12)) >> (shift - 12) from shift 12 up, (A << (12 - shift)) + (B >> shift) below it.  A lane
-// whose sum the reference keeps in 32 bits takes ((A << 12) + B) >> shift, which wraps as that sum does.  One form,
-// ((A << l) + (B >> r1)) >> r2, with three shift counts per lane: two multiply-adds per tap and five more instructions a sample
-// where the 64-bit multiply-add issues once in sixteen cycles, and four threads to a subframe as for the narrow sums.
-template <int T, bool MUL24, bool PAIR, bool SPLIT = false, typename LDS, typename PX>
+template <int T, bool MUL24, bool PAIR, typename LDS, typename PX>
 __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, const PipeOut &O, uint32_t LW, uint32_t tid, uint32_t bs_w, uint32_t need)
 {
 	static_assert(LDS::maxlw == 16 && DEC_LANES == 64, "four threads per subframe, sixteen subframes");
@@ -754,53 +747,13 @@ __device__ __forceinline__ void restore_run_quad(LDS &L, PX &X, const PipeOut &O
 	const uint32_t order = predictive ? X.order[fl] : 0;
 	const int shift = have ? X.shift[fl] : 0;
 	int32_t q[T], h[T];
-	int32_t hh[SPLIT ? T : 1], hl[SPLIT ? T : 1];   // SPLIT: the samples' halves
-	uint32_t sl = 0, sr1 = 0, sr2 = 0;
-	if (SPLIT) {
-		const bool wide_lane = have && (X.flags[fl] & 2u);
-		const uint32_t sh = (uint32_t)shift;
-		sl = wide_lane ? (sh >= 12 ? 0u : 12u - sh) : 12u;
-		sr1 = wide_lane ? (sh >= 12 ? 12u : sh) : 0u;
-		sr2 = wide_lane ? (sh >= 12 ? sh - 12u : 0u) : sh;
-	}
 #pragma unroll
 	for (int u = 0; u < T; u++) {
 		q[u] = 0;
 		h[u] = 0;
-		if (SPLIT) {
-			hh[u] = 0;
-			hl[u] = 0;
-		}
 	}
 	auto step = [&](int32_t res) __attribute__((always_inline)) -> int32_t {
 		int32_t part;
-		if (SPLIT) {
-			int32_t pa, pb;
-			asm("v_mul_i32_i24 %0, %1, %2" : "=v"(pa) : "v"(q[T - 1]), "v"(hh[T - 1]));
-			asm("v_mul_i32_i24 %0, %1, %2" : "=v"(pb) : "v"(q[T - 1]), "v"(hl[T - 1]));
-#pragma unroll
-			for (int u = T - 2; u >= 0; u--) {
-				asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(pa) : "v"(q[u]), "v"(hh[u]), "v"(pa));
-				asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(pb) : "v"(q[u]), "v"(hl[u]), "v"(pb));
-			}
-			pa += __builtin_amdgcn_update_dpp(0, pa, 0x124, 0xf, 0xf, true);   // row_ror:4
-			pb += __builtin_amdgcn_update_dpp(0, pb, 0x124, 0xf, 0xf, true);
-			pa += __builtin_amdgcn_update_dpp(0, pa, 0x128, 0xf, 0xf, true);   // row_ror:8
-			pb += __builtin_amdgcn_update_dpp(0, pb, 0x128, 0xf, 0xf, true);
-			const int32_t pred = (int32_t)(((uint32_t)pa << sl) + (uint32_t)(pb >> sr1)) >> sr2;
-			const int32_t v = (int32_t)((uint32_t)res + (uint32_t)pred);
-			const int32_t in = __builtin_amdgcn_update_dpp(v, h[T - 1], 0x114, 0xf, 0xe, false);
-#pragma unroll
-			for (int u = T - 1; u > 0; u--) {
-				h[u] = h[u - 1];
-				hh[u] = hh[u - 1];
-				hl[u] = hl[u - 1];
-			}
-			h[0] = in;
-			hh[0] = in >> 12;
-			hl[0] = in & 0xfff;
-			return v;
-		}
 		if (MUL24) {
 			asm("v_mul_i32_i24 %0, %1, %2" : "=v"(part) : "v"(q[T - 1]), "v"(h[T - 1]));
 #pragma unroll
@@ -1093,13 +1046,6 @@ __global__ __launch_bounds__((MODE == DEC_PIPE || MODE == DEC_PAIR) ? 2 * DEC_LA
 		else restore_run_quad<T, false, PAIR>(L, X, O, LW, tid, bs_w, need); \
 	} while (0)
 			if (need == 0) RESTORE(0, false);
-			else if (any_wide && all24 && need <= 16) {
-				// (64-bit sums of samples of up to 24 bits: in two halves, four threads to a subframe)
-				if (need <= 4) restore_run_quad<1, true, PAIR, true>(L, X, O, LW, tid, bs_w, need);
-				else if (need <= 8) restore_run_quad<2, true, PAIR, true>(L, X, O, LW, tid, bs_w, need);
-				else if (need <= 12) restore_run_quad<3, true, PAIR, true>(L, X, O, LW, tid, bs_w, need);
-				else restore_run_quad<4, true, PAIR, true>(L, X, O, LW, tid, bs_w, need);
-			}
 			else if (!any_wide) {
 				if (need <= 4) RESTORE_QUAD(1);
 				else if (need <= 8) RESTORE_QUAD(2);
