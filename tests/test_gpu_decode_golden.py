@@ -410,3 +410,33 @@ def test_every_channel_count_and_output_width_comes_back(channels):
                 assert np.array_equal(np.asarray(out, dtype=np.int32), pcm), (channels, bps, bs, osb)
         finally:
             dec.close()
+
+
+@pytest.mark.parametrize("channels,bps,bs", [(1, 8, 16), (2, 16, 16), (2, 16, 192), (1, 16, 4096)])
+def test_header_scan_with_many_and_with_few_headers_per_block(channels, bps, bs):
+    """The scan for frame headers keeps the headers it parses, up to eight per 4 KiB of input, for the pass that puts them in
+    order; a stretch of input with more (frames of sixteen samples are a dozen bytes each: hundreds per 4 KiB) is parsed again.
+    Streams on both sides of that limit, and one whose stretches fall on either side (silence and noise in turn), come back whole."""
+    import flac_amd
+    rng = np.random.default_rng(bs + channels)
+    nframes = 3000 if bs <= 192 else 64
+    n = nframes * bs - bs // 2
+    full = 1 << (bps - 1)
+    pcm = rng.integers(-full // 4, full // 4, size=(n, channels)).astype(np.int32)
+    quarter = n // 4
+    pcm[quarter:2 * quarter] = 0          # constant subframes: the smallest frames there are
+    pcm[3 * quarter:] = 7
+    enc = flac_amd.Encoder(flac_amd.preset(5, channels, bps, 44100, bs), device=0, max_frames=nframes)
+    try:
+        frames, _ = enc.encode_host(pcm)
+    finally:
+        enc.close()
+    assert len(frames) == nframes
+    blob = b"".join(frames)
+    dec = flac_amd.Decoder(channels, bps, bs, device=0, max_input_bytes=len(blob) + 64, max_frames=nframes + 64)
+    try:
+        out, nfr, wide, bad = dec.decode_host(blob, [(0, len(blob), 0, n)], n, out_sample_bytes=4)
+        assert nfr == nframes and wide == n
+        assert np.array_equal(out, pcm)
+    finally:
+        dec.close()
